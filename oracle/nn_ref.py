@@ -1,0 +1,156 @@
+"""Torch fp32 CPU restatement of the reference's policy/value networks.
+
+TEST INFRASTRUCTURE (oracle) -- floating-point reference for the HIP conv
+kernels.  Architecture and state_dict key names follow the reference:
+  ResNetZero  nn.py:108-122 (ResNet :16-30, ResBlock :33-58, PolicyHead :74-87,
+              ValueHead :90-105), shipped config configuration.py:134-156
+  SimpleNN    dots_boxes/dots_boxes_nn.py:61-98
+  predict     NeuralNetWrapper.predict_sync nn.py:155-160 (eval mode, exp(log p))
+
+Parity status: pinned by tests/golden/nn_*.npz (outputs of the reference's own
+modules on committed / seed-regenerated weights).
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+def _conv(cin, cout, k, pad=True):
+    return nn.Conv2d(cin, cout, k, padding=(k - 1) // 2 if pad else 0)
+
+
+class _Block(nn.Module):
+    def __init__(self, ch, k):
+        super().__init__()
+        self.conv1 = _conv(ch, ch, k)
+        self.bn1 = nn.BatchNorm2d(ch)
+        self.conv2 = _conv(ch, ch, k)
+        self.bn2 = nn.BatchNorm2d(ch)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        y = y + x
+        return F.relu(y)
+
+
+class _Tower(nn.Module):
+    def __init__(self, cin, ch, k, nb):
+        super().__init__()
+        self.conv0 = _conv(cin, ch, 3)
+        self.bn0 = nn.BatchNorm2d(ch)
+        self.resblocks = nn.Sequential(*[_Block(ch, k) for _ in range(nb)])
+
+    def forward(self, x):
+        return self.resblocks(F.relu(self.bn0(self.conv0(x))))
+
+
+class _ValueHead(nn.Module):
+    def __init__(self, cin, inner, fc_in, fc_inner):
+        super().__init__()
+        self.conv0 = nn.Conv2d(cin, inner, kernel_size=(1, 1))
+        self.bn0 = nn.BatchNorm2d(inner)
+        self.fc0 = nn.Linear(fc_in, fc_inner)
+        self.fc1 = nn.Linear(fc_inner, 1)
+
+    def forward(self, x):
+        x = F.relu(self.bn0(self.conv0(x)))
+        x = F.relu(self.fc0(x.reshape(x.size(0), -1)))
+        return torch.tanh(self.fc1(x))
+
+
+class _PolicyHead(nn.Module):
+    def __init__(self, cin, inner, fc_in, nb_actions):
+        super().__init__()
+        self.conv0 = nn.Conv2d(cin, inner, kernel_size=(1, 1))
+        self.bn0 = nn.BatchNorm2d(inner)
+        self.fc = nn.Linear(fc_in, nb_actions)
+
+    def forward(self, x):
+        x = F.relu(self.bn0(self.conv0(x)))
+        return F.log_softmax(self.fc(x.reshape(x.size(0), -1)), dim=1)
+
+
+class ResNetZeroRef(nn.Module):
+    """Same module tree / registration order as the reference's ResNetZero, so a
+    reference state_dict loads with strict=True and torch.manual_seed(s) yields the
+    same random init."""
+
+    def __init__(self, rows, cols, channels=64, blocks=20, kernel=3, head_channels=16, value_fc=8,
+                 in_channels=3):
+        super().__init__()
+        H, W = rows + 1, cols + 1
+        self.cfg = dict(rows=rows, cols=cols, channels=channels, blocks=blocks, kernel=kernel,
+                        head_channels=head_channels, value_fc=value_fc, in_channels=in_channels)
+        self.bn_input = nn.BatchNorm2d(in_channels)
+        self.resnet = _Tower(in_channels, channels, kernel, blocks)
+        self.value_head = _ValueHead(channels, head_channels, head_channels * H * W, value_fc)
+        self.policy_head = _PolicyHead(channels, head_channels, head_channels * H * W, 2 * H * W)
+
+    def forward(self, x):
+        x = self.resnet(self.bn_input(x))
+        return self.policy_head(x), self.value_head(x)
+
+
+class SimpleNNRef(nn.Module):
+    """dots_boxes_nn.py:61-98 -- 3x3 boards only; BN follows ReLU."""
+
+    def __init__(self, n_ch=256):
+        super().__init__()
+        self.conv0 = nn.Conv2d(3, n_ch, 3, padding=1)
+        self.bn0 = nn.BatchNorm2d(n_ch)
+        self.conv1 = nn.Conv2d(n_ch, n_ch, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(n_ch)
+        self.conv2 = nn.Conv2d(n_ch, n_ch, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(n_ch)
+        self.conv3 = nn.Conv2d(n_ch, n_ch, 3, padding=1)
+        self.bn3 = nn.BatchNorm2d(n_ch)
+        self.conv4 = nn.Conv2d(n_ch, n_ch, 3, padding=0)
+        self.bn4 = nn.BatchNorm2d(n_ch)
+        self.fc0 = nn.Linear(1024, 512)
+        self.bn_fc0 = nn.BatchNorm1d(512)
+        self.fc1 = nn.Linear(512, 256)
+        self.bn_fc1 = nn.BatchNorm1d(256)
+        self.value_fc = nn.Linear(256, 1)
+        self.policy_fc = nn.Linear(256, 32)
+
+    def forward(self, x):
+        for i in range(5):
+            x = getattr(self, "bn%d" % i)(F.relu(getattr(self, "conv%d" % i)(x)))
+        x = x.reshape(x.size(0), -1)
+        x = self.bn_fc0(F.relu(self.fc0(x)))
+        x = self.bn_fc1(F.relu(self.fc1(x)))
+        return F.log_softmax(self.policy_fc(x), dim=1), torch.tanh(self.value_fc(x))
+
+
+def randomize_bn(model, seed):
+    """Give every BatchNorm non-trivial affine + running statistics (a fresh module
+    has mean 0 / var 1 / gamma 1 / beta 0, which would hide BN bugs).  Deterministic
+    in module registration order; applied identically to reference and restated nets."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                n = m.num_features
+                m.running_mean.copy_(torch.randn(n, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(n, generator=g) * 0.5 + 0.75)
+                m.weight.copy_(torch.rand(n, generator=g) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(n, generator=g) * 0.1)
+    return model
+
+
+def predict_sync(model, X):
+    """NeuralNetWrapper.predict_sync (nn.py:155-160): eval mode, float32 in,
+    (softmax p [n,A], tanh v [n,1]) numpy out."""
+    model.train(False)
+    with torch.no_grad():
+        x = torch.tensor(X, dtype=torch.float32)
+        p, v = model.forward(x)
+        return torch.exp(p).cpu().numpy(), v.cpu().numpy()
+
+
+def state_dict_checksum(model):
+    s = 0.0
+    for _, t in model.state_dict().items():
+        s += float(t.double().abs().sum())
+    return s

@@ -1,0 +1,481 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (the reference lives at /root/reference and
+never travels to the GPU box).  Usage:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [--only rules,mcts,nn,selfplay]
+
+Outputs are data only (inputs + the reference's outputs):
+    rules.npz      seeded random playouts, BoxesState fields after every ply   (G1-G6)
+    boards_csv.npz the 34 move sequences of the reference's test/test_boards.csv
+                   with the resulting states
+    mcts.npz       sequential UCT_search (max_pending_evals=1) root arrays/stats
+                   under a formula-defined evaluator                           (M1-M9)
+    nn.npz         ResNetZero / SimpleNN outputs on committed / seeded weights  (N1-N3)
+    selfplay.npz   SelfPlay.play_game + get_datasets with recorded RNG draws    (D1-D3)
+"""
+import argparse
+import asyncio
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("DBAZ_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+warnings.simplefilter("ignore")
+
+import torch  # noqa: E402
+from dots_boxes.dots_boxes_game import BoxesState  # noqa: E402  (reference)
+import mcts as ref_mcts  # noqa: E402  (reference)
+from oracle import nn_ref  # noqa: E402  (only for randomize_bn / checksum helpers)
+
+M64 = (1 << 64) - 1
+
+
+def set_board(rows, cols):
+    BoxesState.init_static_fields(((rows, cols),))
+
+
+# ---------------------------------------------------------------- formula evaluator
+def fmix64(x):
+    x ^= x >> 33
+    x = (x * 0xFF51AFD7ED558CCD) & M64
+    x ^= x >> 33
+    x = (x * 0xC4CEB9FE1A85EC53) & M64
+    x ^= x >> 33
+    return x
+
+
+def played_bits(state):
+    """Full-width edge bitmask (sum of 1<<move over played moves).  The reference keeps
+    this in BoxesState.hash[0], but `1 << move` wraps at 64 bits whenever `move` is a
+    numpy integer (np.argmax / np.random.choice results), so it is recomputed here from
+    the board with python ints."""
+    b = 0
+    for i, e in enumerate(state.board.ravel().tolist()):
+        if e == 255:
+            b |= 1 << i
+    return b
+
+
+def formula_eval(state, kind):
+    A = state.get_actions_size()
+    if kind == 1:
+        return np.ones(A, dtype=np.float32), np.array([0.0], dtype=np.float32)
+    bits = played_bits(state)
+    b2c2 = int(round(state.boxes_to_close[state.to_play] * 2))
+    h = 0x9E3779B97F4A7C15
+    for w in range(4):
+        h = fmix64(h ^ ((bits >> (64 * w)) & M64))
+    h = fmix64(h ^ ((b2c2 + 512) & M64))
+    p = np.zeros(A, dtype=np.float32)
+    for i in range(A):
+        t = fmix64((h + (i + 1) * 0x9E3779B97F4A7C15) & M64)
+        u = (t >> 20) & 0xFFFF
+        p[i] = np.float32((u & 0xFF) + 1) * np.float32(((u >> 8) & 0xFF) + 1)
+    t = fmix64(h ^ 0xD6E8FEB86659FD93)
+    u = (t >> 17) & 0xFFFF
+    v = (np.float32(u) - np.float32(32768.0)) / np.float32(32768.0)
+    return p, np.array([v], dtype=np.float32)
+
+
+def make_async_formula(kind):
+    async def nn(state):
+        return formula_eval(state, kind)
+    return nn
+
+
+def run(coro):
+    loop = asyncio.new_event_loop()
+    try:
+        return loop.run_until_complete(coro)
+    finally:
+        loop.close()
+
+
+def state_record(s):
+    return dict(board=s.board.copy().ravel(), to_play=s.to_play,
+                just_played=-1 if s.just_played is None else s.just_played,
+                b2c2=[int(round(2 * s.boxes_to_close[0])), int(round(2 * s.boxes_to_close[1]))],
+                result=2 if s.get_result() is None else s.get_result(),
+                valid=s.get_valid_moves().copy(), features=s.get_features().ravel().copy(),
+                hash_b2c2=int(round(2 * s.hash[1])),
+                hash_words=[(played_bits(s) >> (64 * w)) & M64 for w in range(4)])
+
+
+# ---------------------------------------------------------------- rules
+def gen_rules():
+    out = {}
+    rng = np.random.RandomState(1234)
+    boards = [(3, 3), (6, 6), (9, 9), (2, 3), (1, 1), (4, 2)]
+    for (r, c) in boards:
+        set_board(r, c)
+        n_games = 6 if r * c > 1 else 1
+        for gi in range(n_games):
+            s = BoxesState()
+            recs = [state_record(s)]
+            moves, closed_n, closed_lc = [], [], []
+            while True:
+                vm = s.get_valid_moves(as_indices=True)
+                if len(vm) == 0:
+                    break
+                # half of the games stop when the reference reports a result, the
+                # rest play the board out completely (rules stay defined past the end)
+                if gi % 2 == 0 and s.get_result() is not None:
+                    break
+                m = int(vm[rng.randint(len(vm))])
+                cl = s.play_(m)
+                moves.append(m)
+                closed_n.append(len(cl))
+                pad = [x for lc in cl for x in lc] + [-1] * (4 - 2 * len(cl))
+                closed_lc.append(pad)
+                recs.append(state_record(s))
+            key = "b%dx%d_g%d" % (r, c, gi)
+            out[key + "_moves"] = np.array(moves, dtype=np.int16)
+            out[key + "_closed_n"] = np.array(closed_n, dtype=np.int8)
+            out[key + "_closed_lc"] = np.array(closed_lc, dtype=np.int8).reshape(-1, 4)
+            for f in recs[0]:
+                dt = {"board": np.uint8, "valid": np.bool_, "features": np.int16,
+                      "hash_words": np.uint64}.get(f, np.int16)
+                out[key + "_" + f] = np.array([rc[f] for rc in recs], dtype=dt)
+        # an illegal-move case: replaying a played edge / playing a sentinel raises ValueError
+        s = BoxesState()
+        s.play_(0)
+        illegal = []
+        for m in (0, c, 2 * (r + 1) * (c + 1) - 1):
+            try:
+                s.play_(m)
+                illegal.append(0)
+            except ValueError:
+                illegal.append(1)
+        out["b%dx%d_illegal" % (r, c)] = np.array(illegal, dtype=np.int8)
+    out["boards"] = np.array(boards, dtype=np.int16)
+    np.savez_compressed(os.path.join(HERE, "rules.npz"), **out)
+    print("rules.npz", len(out), "arrays")
+
+
+def load_csv():
+    rows = []
+    with open(os.path.join(REF, "test", "test_boards.csv")) as f:
+        for line in f:
+            line = line.strip()
+            if not line or line.startswith("#") or line.startswith("id;"):
+                continue
+            parts = line.split(";")
+            rows.append((int(parts[0]), [int(x) for x in parts[1].split()],
+                         [int(x) for x in parts[2].split()], int(parts[3])))
+    return rows
+
+
+def gen_boards_csv():
+    set_board(3, 3)
+    rows = load_csv()
+    out = {"ids": np.array([r[0] for r in rows], dtype=np.int16),
+           "z": np.array([r[3] for r in rows], dtype=np.int8)}
+    for (i, mv, nxt, _z) in rows:
+        s = BoxesState()
+        for m in mv:
+            s.play_(m)
+        rec = state_record(s)
+        k = "id%d_" % i
+        out[k + "moves"] = np.array(mv, dtype=np.int16)
+        out[k + "next_moves"] = np.array(nxt, dtype=np.int16)
+        out[k + "board"] = rec["board"]
+        out[k + "features"] = rec["features"]
+        out[k + "meta"] = np.array([rec["to_play"], rec["just_played"], rec["b2c2"][0], rec["b2c2"][1],
+                                    rec["result"]], dtype=np.int16)
+    np.savez_compressed(os.path.join(HERE, "boards_csv.npz"), **out)
+    print("boards_csv.npz", len(rows), "positions")
+
+
+# ---------------------------------------------------------------- mcts
+def root_record(node):
+    st = node.get_tree_stats()
+    tv = node.total_value  # TreeRoot slot keyed by node.move (None only for a never re-rooted tree)
+    return dict(priors=np.asarray(node.child_priors, dtype=np.float64).copy(),
+                priors_is_f64=int(np.asarray(node.child_priors).dtype == np.float64),
+                total_value=node.child_total_value.copy(), visits=node.child_number_visits.copy(),
+                changed=node.child_player_changed.copy(),
+                stats_i=np.array([st.max_deepness, st.tree_size, st.terminal_count], dtype=np.int32),
+                q=np.float32(st.q_value),
+                root_tv=np.float32(np.asarray(tv).ravel()[0]),
+                root_nv=np.int32(node.number_visits))
+
+
+def gen_mcts():
+    out = {}
+    cases = []
+
+    def add_case(name, rows, cols, start_moves, kind, script, cpuct=(1.25, 19652)):
+        """script: list of ('search', n, alpha, coeff) / ('advance', move or -1 for argmax, reuse)"""
+        set_board(rows, cols)
+        s = BoxesState()
+        for m in start_moves:
+            s.play_(m)
+        node = ref_mcts.create_root_uct_node(s)
+        nn = make_async_formula(kind)
+        import zlib
+        rng = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
+        A = s.get_actions_size()
+        steps = []
+        si = 0
+        for op in script:
+            if op[0] == "search":
+                _, n, alpha, coeff = op
+                noise = None
+                if alpha > 0:
+                    noise = rng.dirichlet(np.full(A, alpha))
+                    orig = np.random.dirichlet
+                    np.random.dirichlet = lambda a, size=None, _n=noise: _n.reshape(1, -1).copy()
+                try:
+                    vc = run(ref_mcts.UCT_search(node, n, nn, cpuct, 1, (alpha, coeff)))
+                finally:
+                    if alpha > 0:
+                        np.random.dirichlet = orig
+                rec = root_record(node)
+                assert np.array_equal(vc, rec["visits"])
+                k = "%s_s%d_" % (name, si)
+                for f, v in rec.items():
+                    out[k + f] = np.asarray(v)
+                out[k + "noise"] = noise if noise is not None else np.zeros(0)
+                steps.append((0, n, alpha, coeff))
+            else:
+                _, mv, reuse = op
+                if mv < 0:
+                    mv = int(np.argmax(node.child_number_visits))
+                node = ref_mcts.init_mcts_tree(node, mv, reuse_tree=bool(reuse))
+                steps.append((1, mv, float(reuse), 0.0))
+            si += 1
+        out[name + "_script"] = np.array(steps, dtype=np.float64)
+        out[name + "_cfg"] = np.array([rows, cols, kind, cpuct[0], cpuct[1]], dtype=np.float64)
+        out[name + "_start"] = np.array(start_moves, dtype=np.int16)
+        cases.append(name)
+
+    S = lambda n, a=0.0, c=0.0: ("search", n, a, c)  # noqa: E731
+    ADV = lambda mv=-1, reuse=1: ("advance", mv, reuse)  # noqa: E731
+    for n in (1, 2, 25, 100, 800):
+        add_case("e33_k0_n%d" % n, 3, 3, [], 0, [S(n)])
+    add_case("e33_k1_n25", 3, 3, [], 1, [S(25)])
+    add_case("e33_k1_n200", 3, 3, [], 1, [S(200)])
+    csv = {r[0]: r for r in load_csv()}
+    for cid in (1, 2, 3, 4, 5, 6, -1, -5, -10, -20, -24):
+        add_case("csv%s_k0_n100" % str(cid).replace("-", "m"), 3, 3, csv[cid][1], 0, [S(100)])
+    add_case("csv5_k1_n300", 3, 3, csv[5][1], 1, [S(300)])
+    add_case("e66_k0_n25", 6, 6, [], 0, [S(25)])
+    add_case("e66_k0_n800", 6, 6, [], 0, [S(800)])
+    add_case("e66_k1_n200", 6, 6, [], 1, [S(200)])
+    add_case("e99_k0_n200", 9, 9, [], 0, [S(200)])
+    add_case("e23_k0_n100", 2, 3, [], 0, [S(100)])
+    add_case("e11_k0_n30", 1, 1, [], 0, [S(30)])
+    # tree reuse / fresh-root sequences, repeated searches on one root, injected noise
+    add_case("seq33_reuse", 3, 3, [], 0, [S(100), ADV(), S(100), ADV(), S(60), ADV(), S(100), ADV(), S(100), ADV(),
+                                          S(100), ADV(), S(100), ADV(), S(100)])
+    add_case("seq33_fresh", 3, 3, [], 0, [S(80), ADV(-1, 0), S(80), ADV(-1, 0), S(80), ADV(-1, 0), S(80)])
+    add_case("seq33_noise", 3, 3, [], 0, [S(50, 0.8, 0.25), ADV(), S(50, 0.8, 0.25), ADV(), S(50, 0.8, 0.25),
+                                          ADV(), S(50, 0.8, 0.25)])
+    add_case("seq33_repeat", 3, 3, [], 0, [S(40), S(40), S(40, 0.8, 0.25), S(40, 0.8, 0.25), S(40)])
+    add_case("seq33_unvisited", 3, 3, [], 0, [S(10), ADV(27, 1), S(10), ADV(26, 0), S(10)])
+    add_case("seq66_reuse", 6, 6, [], 0, [S(200), ADV(), S(200), ADV(), S(200), ADV(), S(200)])
+    add_case("seq66_noise", 6, 6, [], 0, [S(150, 0.8, 0.25), ADV(), S(150, 0.8, 0.25), ADV(), S(150, 0.8, 0.25)])
+    add_case("seq99_reuse", 9, 9, [], 0, [S(120, 0.8, 0.25), ADV(), S(120), ADV(), S(120)])
+    add_case("cp33", 3, 3, [], 0, [S(120)], cpuct=(2.0, 500))
+    # endgame: searches hit the 4*n! rule region and terminal leaves dominate
+    add_case("end33", 3, 3, csv[4][1], 0, [S(60), ADV(), S(60), ADV(), S(24), ADV(), S(8)])
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "mcts.npz"), **out)
+    print("mcts.npz", len(cases), "cases")
+
+
+# ---------------------------------------------------------------- nn
+def ref_resnet_params(rows, cols, channels, blocks, head_ch, value_fc):
+    from utils.utils import DotDict
+    H, W = rows + 1, cols + 1
+    return DotDict({"nn": {"model_parameters": {
+        "resnet": {"pad_layer0": True, "in_channels": 3, "nb_channels": channels, "inner_channels": None,
+                   "kernel_size": 3, "nb_blocks": blocks, "n_groups": 1},
+        "policy_head": {"in_channels": channels, "inner_channels": head_ch, "fc_in": head_ch * H * W,
+                        "nb_actions": 2 * H * W},
+        "value_head": {"in_channels": channels, "inner_channels": head_ch, "fc_in": head_ch * H * W,
+                       "fc_inner": value_fc}}, "pytorch_device": "cpu"}})
+
+
+def sample_features(rows, cols, n, seed):
+    """features of positions reached by seeded random playouts (real NN inputs)"""
+    set_board(rows, cols)
+    rng = np.random.RandomState(seed)
+    X = []
+    while len(X) < n:
+        s = BoxesState()
+        while s.get_result() is None and len(X) < n:
+            if rng.rand() < 0.5:
+                X.append(s.get_features().copy())
+            vm = s.get_valid_moves(as_indices=True)
+            s.play_(int(vm[rng.randint(len(vm))]))
+    return np.stack(X, axis=0).astype(np.int16)
+
+
+def gen_nn():
+    import nn as ref_nn
+    from dots_boxes.dots_boxes_nn import SimpleNN
+    out = {}
+    torch.set_num_threads(1)
+    # (a) reduced ResNetZero with COMMITTED weights, three boards
+    for (r, c, ch, nb, hc, vf, tag) in ((3, 3, 16, 2, 4, 8, "small33"), (6, 6, 16, 2, 4, 8, "small66"),
+                                        (2, 3, 8, 1, 4, 4, "small23")):
+        torch.manual_seed(7)
+        params = ref_resnet_params(r, c, ch, nb, hc, vf)
+        model = ref_nn.ResNetZero(params)
+        nn_ref.randomize_bn(model, 11)
+        wrapper = ref_nn.NeuralNetWrapper(model, params)
+        X = sample_features(r, c, 12, 5)
+        p, v = wrapper.predict_sync(X)
+        out[tag + "_cfg"] = np.array([r, c, ch, nb, hc, vf], dtype=np.int32)
+        out[tag + "_X"] = X
+        out[tag + "_p"] = p
+        out[tag + "_v"] = v
+        for k, t in model.state_dict().items():
+            out[tag + "_w_" + k] = t.numpy()
+    # (b) full-size ResNetZero 20x64 -- weights regenerated from the seed, only I/O stored
+    for (r, c, tag) in ((3, 3, "full33"), (6, 6, "full66"), (9, 9, "full99")):
+        torch.manual_seed(0)
+        params = ref_resnet_params(r, c, 64, 20, 16, 8)
+        model = ref_nn.ResNetZero(params)
+        nn_ref.randomize_bn(model, 3)
+        wrapper = ref_nn.NeuralNetWrapper(model, params)
+        X = sample_features(r, c, 8, 9)
+        p, v = wrapper.predict_sync(X)
+        out[tag + "_cfg"] = np.array([r, c, 64, 20, 16, 8], dtype=np.int32)
+        out[tag + "_X"] = X
+        out[tag + "_p"] = p
+        out[tag + "_v"] = v
+        out[tag + "_checksum"] = np.float64(nn_ref.state_dict_checksum(model))
+    # (c) SimpleNN (3x3 only), seed-regenerated weights
+    set_board(3, 3)
+    torch.manual_seed(0)
+    model = SimpleNN(None)
+    nn_ref.randomize_bn(model, 3)
+    from utils.utils import DotDict
+    wrapper = ref_nn.NeuralNetWrapper(model, DotDict({"nn": {"pytorch_device": "cpu"}}))
+    X = sample_features(3, 3, 8, 9)
+    p, v = wrapper.predict_sync(X)
+    out["simple_X"] = X
+    out["simple_p"] = p
+    out["simple_v"] = v
+    out["simple_checksum"] = np.float64(nn_ref.state_dict_checksum(model))
+    np.savez_compressed(os.path.join(HERE, "nn.npz"), **out)
+    print("nn.npz", len(out), "arrays")
+
+
+# ---------------------------------------------------------------- self-play
+def gen_selfplay():
+    import self_play as ref_sp
+    import nn as ref_nn
+    from utils.utils import DotDict
+    out = {}
+    cases = []
+
+    def run_case(name, rows, cols, sims, noise, reuse, n_games, seed, evaluator, temperature=None):
+        set_board(rows, cols)
+        temperature = {0: 1.0, 12: 0.02} if temperature is None else temperature
+        params = DotDict({"self_play": {"reuse_mcts_tree": bool(reuse), "noise": list(noise),
+                                        "mcts": {"mcts_num_read": sims, "mcts_cpuct": [1.25, 19652],
+                                                 "temperature": dict(temperature), "max_async_searches": 1}}})
+        np.random.seed(seed)
+        drawn_noise, drawn_moves = [], []
+        o_dir, o_ch = np.random.dirichlet, np.random.choice
+
+        def rec_dir(alpha, size=None):
+            r = o_dir(alpha, size)
+            drawn_noise.append(np.asarray(r).ravel().copy())
+            return r
+
+        def rec_choice(a, size=None, replace=True, p=None):
+            r = o_ch(a, size, replace, p)
+            drawn_moves.append(int(np.asarray(r).ravel()[0]))
+            return r
+
+        np.random.dirichlet, np.random.choice = rec_dir, rec_choice
+        try:
+            sp = ref_sp.SelfPlay(evaluator, params)
+            run(sp.play_games(BoxesState(), list(range(n_games))))
+        finally:
+            np.random.dirichlet, np.random.choice = o_dir, o_ch
+        df = sp.get_datasets(3, with_features=True).reset_index()
+        A = 2 * (rows + 1) * (cols + 1)
+        F = 3 * (rows + 1) * (cols + 1)
+        k = name + "_"
+        out[k + "cfg"] = np.array([rows, cols, sims, noise[0], noise[1], int(reuse), n_games, seed], dtype=np.float64)
+        out[k + "temp"] = np.array(sorted(temperature.items()), dtype=np.float64)
+        out[k + "index"] = df[["generation", "game_idx", "move_idx"]].to_numpy().astype(np.int16)
+        out[k + "move"] = df["move"].to_numpy().astype(np.int16)
+        out[k + "player"] = df["player"].to_numpy().astype(np.int8)
+        out[k + "x"] = df[["x_%d" % i for i in range(F)]].to_numpy().astype(np.int16)
+        out[k + "pi"] = df[["pi_%d" % i for i in range(A)]].to_numpy().astype(np.float64)
+        out[k + "z"] = df["z"].to_numpy().astype(np.int64)
+        out[k + "stats"] = df[["max_deepness", "tree_size", "terminal_count"]].to_numpy().astype(np.int32)
+        out[k + "q"] = df["q_value"].to_numpy().astype(np.float32)
+        out[k + "drawn_moves"] = np.array(drawn_moves, dtype=np.int16)
+        out[k + "drawn_noise"] = (np.stack(drawn_noise) if drawn_noise else np.zeros((0, A)))
+        out[k + "dtypes"] = np.array([str(df[c].dtype) for c in ("move", "player", "x_0", "pi_0", "z", "max_deepness",
+                                                                    "tree_size", "terminal_count", "q_value")])
+        cases.append(name)
+        print("  ", name, "rows", len(df))
+
+    run_case("sp33_formula_noise", 3, 3, 25, (0.8, 0.25), True, 2, 0, make_async_formula(0))
+    run_case("sp33_formula_fresh", 3, 3, 25, (0.0, 0.0), False, 2, 1, make_async_formula(0))
+    run_case("sp33_uniform", 3, 3, 40, (0.8, 0.25), True, 1, 2, make_async_formula(1))
+    run_case("sp66_formula", 6, 6, 100, (0.8, 0.25), True, 1, 3, make_async_formula(0))
+    run_case("sp23_formula", 2, 3, 60, (0.8, 0.25), True, 2, 4, make_async_formula(0), temperature={0: 1.0, 4: 0.02})
+
+    # BASELINE config 1: 3x3, 1 game, 25 sims, random-init ResNetZero (reduced size so that
+    # the per-leaf outputs can be committed); every (hash -> p, v) the reference's net
+    # returned is recorded so that the test evaluator is bit-exact on any host.
+    set_board(3, 3)
+    torch.set_num_threads(1)
+    torch.manual_seed(7)
+    params = ref_resnet_params(3, 3, 16, 2, 4, 8)
+    model = ref_nn.ResNetZero(params)
+    nn_ref.randomize_bn(model, 11)
+    wrapper = ref_nn.NeuralNetWrapper(model, params)
+    log_k, log_p, log_v = [], [], []
+
+    async def net(state):
+        p, v = wrapper.predict_sync(np.stack([state.get_features()], axis=0))
+        bits = played_bits(state)
+        log_k.append([(bits >> (64 * w)) & M64 for w in range(4)] +
+                     [(int(round(2 * state.boxes_to_close[state.to_play])) + 512) & M64])
+        log_p.append(p[0].copy())
+        log_v.append(v[0].copy())
+        return p[0], v[0]
+
+    run_case("sp33_resnet", 3, 3, 25, (0.8, 0.25), True, 1, 0, net)
+    out["sp33_resnet_evalkeys"] = np.array(log_k, dtype=np.uint64)
+    out["sp33_resnet_evalp"] = np.stack(log_p).astype(np.float32)
+    out["sp33_resnet_evalv"] = np.stack(log_v).astype(np.float32)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "selfplay.npz"), **out)
+    print("selfplay.npz", len(cases), "cases")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="rules,boards,mcts,nn,selfplay")
+    args = ap.parse_args()
+    todo = args.only.split(",")
+    if "rules" in todo:
+        gen_rules()
+    if "boards" in todo:
+        gen_boards_csv()
+    if "mcts" in todo:
+        gen_mcts()
+    if "nn" in todo:
+        gen_nn()
+    if "selfplay" in todo:
+        gen_selfplay()

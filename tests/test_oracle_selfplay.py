@@ -1,0 +1,109 @@
+"""Oracle SelfPlay driver vs golden vectors of the reference's self_play.py
+(play_game :51-74, get_next_move :27-35, get_datasets :95-156) -- rows D1-D3."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from conftest import load_golden
+
+_G = load_golden("selfplay.npz")
+CASES = [str(c) for c in _G["cases"]]
+
+
+def golden_games(g, name):
+    """Split a golden DataFrame dump into per-game slices + the RNG draws of each game."""
+    idx = g[name + "_index"]
+    n_games = int(g[name + "_cfg"][6])
+    moves = g[name + "_drawn_moves"]
+    noise = g[name + "_drawn_noise"]
+    out = []
+    pos = 0
+    for gi in range(n_games):
+        rows = np.where(idx[:, 1] == gi)[0]
+        n = len(rows)
+        out.append(dict(rows=rows, moves=moves[pos:pos + n], noise=noise[pos:pos + n] if len(noise) else None))
+        pos += n
+    assert pos == len(moves)
+    return out
+
+
+def params_of(g, name):
+    rows, cols, sims, a, c, reuse, _n, _seed = g[name + "_cfg"]
+    temp = {int(k): float(v) for k, v in g[name + "_temp"]}
+    d = O.dims(int(rows), int(cols))
+    pp = O.selfplay_params(int(sims), (1.25, 19652), (a, c), bool(reuse), temp)
+    return d, pp
+
+
+def evaluator_of(g, name):
+    if name == "sp33_resnet":
+        table = {}
+        for k, p, v in zip(g[name + "_evalkeys"], g[name + "_evalp"], g[name + "_evalv"]):
+            table[tuple(int(x) for x in k)] = (p, v)
+
+        def fn(d, s):
+            key = tuple(int(s.hash_bits[w]) for w in range(4)) + ((s.b2c2[s.to_play] + 512) & (2 ** 64 - 1),)
+            return table[key]
+        return O.Evaluator(fn)
+    return O.Evaluator(1 if name == "sp33_uniform" else 0)
+
+
+def check_rows(g, name, gg, got):
+    r = gg["rows"]
+    assert got["n_rows"] == len(r)
+    assert np.array_equal(got["move"], g[name + "_move"][r])
+    assert np.array_equal(got["player"], g[name + "_player"][r])
+    assert np.array_equal(got["x"], g[name + "_x"][r])
+    assert np.array_equal(got["pi"].view(np.uint64), g[name + "_pi"][r].view(np.uint64))
+    assert np.array_equal(got["z"], g[name + "_z"][r])
+    st = np.stack([got["max_deepness"], got["tree_size"], got["terminal_count"]], axis=1)
+    assert np.array_equal(st, g[name + "_stats"][r])
+    assert np.array_equal(got["q_value"].view(np.uint32), g[name + "_q"][r].view(np.uint32))
+    assert np.array_equal(np.arange(len(r)), g[name + "_index"][r, 2])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_teacher_forced(name):
+    """Moves and Dirichlet vectors drawn by the reference are injected."""
+    g = _G
+    d, pp = params_of(g, name)
+    ev = evaluator_of(g, name)
+    for gg in golden_games(g, name):
+        it = iter(gg["noise"]) if gg["noise"] is not None else None
+        got = O.play_game(d, pp, ev, forced_moves=gg["moves"],
+                          noise=(lambda n, a: next(it)) if it is not None else None)
+        assert np.array_equal(got["played"], gg["moves"])
+        check_rows(g, name, gg, got)
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c != "sp33_resnet"])
+def test_seed_only(name):
+    """Replaying numpy's global RNG stream (np.random.seed + dirichlet/choice in the
+    reference's call order) reproduces the reference's games from the seed alone."""
+    g = _G
+    d, pp = params_of(g, name)
+    ev = evaluator_of(g, name)
+    np.random.seed(int(g[name + "_cfg"][7]))
+    for gg in golden_games(g, name):
+        got = O.play_game(d, pp, ev,
+                          choice=lambda p: np.random.choice(p.shape[0], 1, p=p)[0],
+                          noise=lambda n, a: np.random.dirichlet(np.full(n, a), 1).ravel())
+        assert np.array_equal(got["played"], gg["moves"])
+        check_rows(g, name, gg, got)
+
+
+def test_dataset_dtypes_documented():
+    """get_datasets column dtypes the drop-in shim must reproduce (self_play.py:119-152)."""
+    dt = [str(x) for x in _G["sp33_formula_noise_dtypes"]]
+    assert dt == ["int16", "int8", "int16", "float64", "int64", "int16", "int32", "int32", "float32"]
+
+
+def test_builtin_rng_hooks_play_legal_games():
+    d = O.dims(3, 3)
+    pp = O.selfplay_params(30, noise=(0.8, 0.25))
+    got = O.play_game(d, pp, O.Evaluator(0), rng_state=12345)
+    assert got["n_rows"] >= 9 and got["result"] in (0, 1)
+    s = O.new_state(d)
+    for m in got["played"]:
+        O.play_(d, s, int(m))
+    assert O.get_result(s) == got["result"]
