@@ -1,0 +1,22 @@
+// nn.h -- policy/value network on HIP (nn.hip): ResNetZero (nn.py:108-122) and
+// SimpleNN (dots_boxes_nn.py:61-98) forward passes, eval-mode BN folded on the host.
+#pragma once
+#include <string>
+
+#include "common.h"
+
+struct NNState;
+
+NNState *nn_create(const Geo &g, int max_batch, int precision);
+void nn_destroy(NNState *nn);
+int nn_configure(NNState *nn, int kind, int channels, int blocks, int head_channels, int value_fc, std::string &err);
+int nn_set_tensor(NNState *nn, const char *key, const float *data, int64_t numel, std::string &err);
+int nn_commit(NNState *nn, hipStream_t s, std::string &err);
+bool nn_ready(const NNState *nn);
+// Evaluate samples feat[list[j]] (float32 planes [3][H][W], j < *n_dev <= max_n) and scatter
+// softmax policy to P[list[j]*AS + a] and tanh value to V[list[j]].  list == nullptr: identity.
+// ev_begin/ev_end (optional) are recorded around the conv tower on `s`.
+void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *list_dev, const int32_t *n_dev,
+                int max_n, float *P, float *V, int AS, hipEvent_t ev_begin, hipEvent_t ev_end);
+double nn_flops_per_sample(const NNState *nn);
+const char *nn_tower_kernel_name(const NNState *nn);

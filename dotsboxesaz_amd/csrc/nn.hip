@@ -1,0 +1,567 @@
+// nn.hip -- policy/value network forward on gfx950 (CDNA4).
+//
+// ResNetZero (reference nn.py:108-122): bn_input -> conv3x3(3->C)+BN+ReLU ->
+//   blocks x [conv3x3+BN+ReLU, conv3x3+BN, +x, ReLU] -> policy head (conv1x1+BN+ReLU,
+//   FC, softmax) / value head (conv1x1+BN+ReLU, FC, ReLU, FC, tanh); predict contract
+//   NeuralNetWrapper.predict_sync (nn.py:155-160): eval-mode BN, p = exp(log_softmax).
+//
+// Layout: activations NHWC float32 [sample][H*W][C]; eval-mode BatchNorms that FOLLOW a
+// conv are folded into its weights/bias on the host (double precision); bn_input is
+// applied to the in-bounds pixels when conv0 stages its input (zero padding happens after
+// bn_input in the reference, so it cannot be folded into conv0's bias).
+//
+// k_conv3x3 is the dominant kernel: an implicit GEMM  Out^T[cout][pos] = W[cout][tap,cin] *
+// In[tap,cin][pos]  on v_mfma_f32_16x16x4_f32 (exact f32: bitwise a k-ordered fmaf chain).
+// A operand = weights, pre-packed on the host in fragment order and streamed from L2
+// straight into registers (each wave owns one 16-cout tile, so no wave re-reads another
+// wave's weights); B operand = activations of S whole samples staged once in LDS
+// (row stride C+8 dwords => conflict-free ds_read_b128) and re-read for the 9 taps;
+// out-of-image taps read a shared zero row.  The accumulator layout puts 4 consecutive
+// couts of one position in each lane, so the epilogue (bias, residual, ReLU) is float4.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "nn.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CONV_THREADS 256
+#define MAXT 13 // position tiles (16 rows each) per workgroup
+
+struct ConvLayer {
+    float *w = nullptr;    // packed [C/16][9][C/16][64][4]
+    float *bias = nullptr; // [C]  (conv bias with BN folded)
+    float *post_s = nullptr, *post_t = nullptr; // SimpleNN: affine applied AFTER ReLU
+};
+
+struct NNState {
+    Geo g;
+    int max_batch = 0, precision = 0;
+    int kind = 0, C = 0, blocks = 0, hc = 0, vf = 0;
+    bool ready = false;
+    std::map<std::string, std::vector<float>> sd;
+    // device
+    std::vector<void *> allocs;
+    float *actA = nullptr, *actB = nullptr, *actC = nullptr;
+    float *in_s = nullptr, *in_t = nullptr;     // bn_input affine [3]
+    float *w0 = nullptr, *b0 = nullptr;         // conv0 [9][3][C], [C]
+    std::vector<ConvLayer> tower;               // 2*blocks
+    float *hw = nullptr, *hb = nullptr;         // head conv1x1: [2*hc][C], [2*hc]
+    float *hact = nullptr;                      // [batch][2][hc*HW]
+    float *wp = nullptr, *bp = nullptr;         // policy FC transposed [hc*HW][A], [A]
+    float *wv0 = nullptr, *bv0 = nullptr;       // value FC0 transposed [hc*HW][vf], [vf]
+    float *wv1 = nullptr, *bv1 = nullptr;       // [vf], [1]
+    int S = 1, NT = 1;                          // samples / position tiles per conv workgroup
+    size_t conv_lds = 0;
+};
+
+// ------------------------------------------------------------------------------------
+// conv0: 3 -> C, VALU (K = 27), bn_input fused on load, BN0 folded, ReLU
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_conv0(Geo g, int C, const float *__restrict__ feat, const int32_t *list,
+                                               const int32_t *n_dev, const float *in_s, const float *in_t,
+                                               const float *__restrict__ w /*[9][3][C]*/, const float *__restrict__ b,
+                                               float *__restrict__ out)
+{
+    extern __shared__ float lds0[];
+    const int j = blockIdx.x;
+    if (j >= *n_dev) return;
+    const int src = list ? list[j] : j;
+    const int H = g.H, W = g.W, HW = g.HW, PW = W + 2, PH = H + 2;
+    float *pad = lds0;                 // [3][PH][PW]
+    float *wl = lds0 + 3 * PH * PW;    // [27][C]
+    for (int i = threadIdx.x; i < 3 * PH * PW; i += blockDim.x) pad[i] = 0.0f;
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+    const float *f = feat + (size_t)src * 3 * HW;
+    for (int i = threadIdx.x; i < 3 * HW; i += blockDim.x) {
+        int c = i / HW, p = i - c * HW, y = p / W, x = p - y * W;
+        pad[(c * PH + y + 1) * PW + x + 1] = f[i] * in_s[c] + in_t[c];
+    }
+    __syncthreads();
+    float *o = out + (size_t)j * HW * C;
+    for (int i = threadIdx.x; i < HW * C; i += blockDim.x) {
+        int p = i / C, co = i - p * C, y = p / W, x = p - y * W;
+        float acc = b[co];
+        for (int tap = 0; tap < 9; tap++) {
+            int dy = tap / 3, dx = tap - dy * 3;
+            for (int c = 0; c < 3; c++)
+                acc += pad[(c * PH + y + dy) * PW + x + dx] * wl[(tap * 3 + c) * C + co];
+        }
+        o[i] = fmaxf(acc, 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// conv3x3 C -> C on MFMA (f32 exact)
+// ------------------------------------------------------------------------------------
+// flags: 1 = add residual before ReLU; 2 = ReLU; 4 = post affine after ReLU (SimpleNN)
+template <int C>
+__global__ void __launch_bounds__(CONV_THREADS) k_conv3x3(Geo g, int S, int NT, const int32_t *n_dev,
+                                                          const float *__restrict__ in, const float *__restrict__ wpk,
+                                                          const float *__restrict__ bias, const float *__restrict__ res,
+                                                          const float *__restrict__ post_s, const float *__restrict__ post_t,
+                                                          float *__restrict__ out, int flags)
+{
+    extern __shared__ float lds[];
+    constexpr int STRIDE = C + 8;    // dwords per LDS row
+    constexpr int KC = C / 16;       // 16-cin chunks per tap
+    const int n = *n_dev;
+    const int s0 = blockIdx.x * S;
+    if (s0 >= n) return;
+    const int HW = g.HW, W = g.W, H = g.H;
+    const int ns = min(S, n - s0);
+    const int R = ns * HW;           // valid rows in this workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- stage the samples' activations: rows [0, R) ; row S*HW is the shared zero row
+    const int zrow = S * HW;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(in + (size_t)s0 * HW * C);
+        const int nv = R * (C / 4);
+        for (int i = tid; i < nv; i += CONV_THREADS) {
+            int r = i / (C / 4), c4 = i - r * (C / 4);
+            float4 v = src[i];
+            *reinterpret_cast<float4 *>(lds + r * STRIDE + c4 * 4) = v;
+        }
+        for (int i = tid; i < STRIDE; i += CONV_THREADS) lds[zrow * STRIDE + i] = 0.0f;
+    }
+    __syncthreads();
+    const int jrow = lane & 15, gq = lane >> 4;
+    // per position tile: (y, x) of this lane's row, or invalid
+    int ty[MAXT], tx[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        int row = t * 16 + jrow;
+        bool ok = (t < NT) && (row < R);
+        int pos = row % HW;
+        ty[t] = ok ? pos / W : -1000;
+        tx[t] = pos % W;
+    }
+    for (int ct = wave; ct < C / 16; ct += CONV_THREADS / 64) {
+        f32x4 acc[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float4 *wbase = reinterpret_cast<const float4 *>(wpk) + (size_t)ct * 9 * KC * 64 + lane;
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int addr[MAXT];
+#pragma unroll
+            for (int t = 0; t < MAXT; t++) {
+                int yy = ty[t] + dy, xx = tx[t] + dx;
+                bool ok = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+                int row = t * 16 + jrow + dy * W + dx;
+                addr[t] = (ok ? row : zrow) * STRIDE + gq * 4;
+            }
+#pragma unroll 2
+            for (int kc = 0; kc < KC; kc++) {
+                const float4 a = wbase[(size_t)(tap * KC + kc) * 64];
+                f32x4 bfr[MAXT];
+#pragma unroll
+                for (int t = 0; t < MAXT; t++)
+                    if (t < NT) bfr[t] = *reinterpret_cast<const f32x4 *>(lds + addr[t] + kc * 16);
+#pragma unroll
+                for (int t = 0; t < MAXT; t++)
+                    if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bfr[t][0], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MAXT; t++)
+                    if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bfr[t][1], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MAXT; t++)
+                    if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bfr[t][2], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MAXT; t++)
+                    if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bfr[t][3], acc[t], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: lane holds couts ct*16 + 4*gq .. +3 of position row t*16 + jrow
+        const int co = ct * 16 + gq * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(bias + co);
+        float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (flags & 4) {
+            ps = *reinterpret_cast<const float4 *>(post_s + co);
+            pt = *reinterpret_cast<const float4 *>(post_t + co);
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; t++) {
+            int row = t * 16 + jrow;
+            if (t < NT && row < R) {
+                size_t off = ((size_t)s0 * HW + row) * C + co;
+                float4 v = make_float4(acc[t][0] + bv.x, acc[t][1] + bv.y, acc[t][2] + bv.z, acc[t][3] + bv.w);
+                if (flags & 1) {
+                    const float4 r4 = *reinterpret_cast<const float4 *>(res + off);
+                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                }
+                if (flags & 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (flags & 4) { v.x = v.x * ps.x + pt.x; v.y = v.y * ps.y + pt.y; v.z = v.z * ps.z + pt.z; v.w = v.w * ps.w + pt.w; }
+                *reinterpret_cast<float4 *>(out + off) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// heads
+// ------------------------------------------------------------------------------------
+// conv1x1 (C -> hc) + folded BN + ReLU for both heads; output in the reference's
+// flatten order x.view(n, -1) of [hc, H, W]:  hact[j][head][c*HW + pos]
+__global__ void __launch_bounds__(256) k_head_conv(Geo g, int C, int hc, const int32_t *n_dev, const float *__restrict__ act,
+                                                   const float *__restrict__ hw, const float *__restrict__ hb,
+                                                   float *__restrict__ hact)
+{
+    extern __shared__ float ldsh[];
+    const int j = blockIdx.x;
+    if (j >= *n_dev) return;
+    const int HW = g.HW;
+    float *wl = ldsh;                 // [2*hc][C+1]
+    float *al = ldsh + 2 * hc * (C + 1); // [HW][C+1]
+    for (int i = threadIdx.x; i < 2 * hc * C; i += blockDim.x) {
+        int o = i / C, c = i - o * C;
+        wl[o * (C + 1) + c] = hw[i];
+    }
+    const float *a = act + (size_t)j * HW * C;
+    for (int i = threadIdx.x; i < HW * C; i += blockDim.x) {
+        int p = i / C, c = i - p * C;
+        al[p * (C + 1) + c] = a[i];
+    }
+    __syncthreads();
+    float *o = hact + (size_t)j * 2 * hc * HW;
+    for (int i = threadIdx.x; i < 2 * hc * HW; i += blockDim.x) {
+        int oc = i / HW, p = i - oc * HW; // oc in [0, 2*hc): head = oc / hc
+        float acc = hb[oc];
+        for (int c = 0; c < C; c++) acc += al[p * (C + 1) + c] * wl[oc * (C + 1) + c];
+        o[i] = fmaxf(acc, 0.0f);
+    }
+}
+
+// policy FC + softmax, value FC0 + ReLU + FC1 + tanh; one block per sample
+__global__ void __launch_bounds__(256) k_head_fc(Geo g, int hc, int vf, int AS, const int32_t *list, const int32_t *n_dev,
+                                                 const float *__restrict__ hact, const float *__restrict__ wp,
+                                                 const float *__restrict__ bp, const float *__restrict__ wv0,
+                                                 const float *__restrict__ bv0, const float *__restrict__ wv1,
+                                                 const float *__restrict__ bv1, float *__restrict__ P, float *__restrict__ V)
+{
+    extern __shared__ float ldsf[];
+    const int j = blockIdx.x;
+    if (j >= *n_dev) return;
+    const int dst = list ? list[j] : j;
+    const int HW = g.HW, A = g.A, K = hc * HW;
+    float *hp = ldsf;          // [K]
+    float *hv = ldsf + K;      // [K]
+    float *red = ldsf + 2 * K; // [256 + vf]
+    const float *h = hact + (size_t)j * 2 * K;
+    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) ldsf[i] = h[i];
+    __syncthreads();
+    const int t = threadIdx.x;
+    float logit = -INFINITY;
+    if (t < A) {
+        float acc = bp[t];
+        for (int k = 0; k < K; k++) acc += hp[k] * wp[(size_t)k * A + t];
+        logit = acc;
+    }
+    // value hidden units on the threads after the policy ones
+    if (t >= 256 - vf) {
+        int u = t - (256 - vf);
+        float acc = bv0[u];
+        for (int k = 0; k < K; k++) acc += hv[k] * wv0[(size_t)k * vf + u];
+        red[256 + u] = fmaxf(acc, 0.0f);
+    }
+    red[t] = logit;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+        __syncthreads();
+    }
+    const float mx = red[0];
+    __syncthreads();
+    const float ex = (t < A) ? expf(logit - mx) : 0.0f;
+    red[t] = ex;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    const float sum = red[0];
+    if (t < A) P[(size_t)dst * AS + t] = ex / sum;
+    if (t == 0) {
+        float acc = bv1[0];
+        for (int u = 0; u < vf; u++) acc += red[256 + u] * wv1[u];
+        V[dst] = tanhf(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+template <typename T>
+static T *nn_alloc(NNState *nn, size_t count)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)) != hipSuccess) return nullptr;
+    nn->allocs.push_back(p);
+    return (T *)p;
+}
+template <typename T>
+static T *nn_upload(NNState *nn, const std::vector<T> &h)
+{
+    T *d = nn_alloc<T>(nn, h.size());
+    if (d && !h.empty()) (void)hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+
+NNState *nn_create(const Geo &g, int max_batch, int precision)
+{
+    NNState *nn = new NNState();
+    nn->g = g;
+    nn->max_batch = max_batch;
+    nn->precision = precision;
+    return nn;
+}
+
+static void nn_free_device(NNState *nn)
+{
+    for (void *p : nn->allocs) (void)hipFree(p);
+    nn->allocs.clear();
+    nn->tower.clear();
+    nn->ready = false;
+}
+
+void nn_destroy(NNState *nn)
+{
+    if (!nn) return;
+    nn_free_device(nn);
+    delete nn;
+}
+
+bool nn_ready(const NNState *nn) { return nn && nn->ready; }
+
+int nn_configure(NNState *nn, int kind, int channels, int blocks, int head_channels, int value_fc, std::string &err)
+{
+    if (kind != DBAZ_EVAL_RESNET) { err = "only DBAZ_EVAL_RESNET is implemented in this build"; return DBAZ_EINVAL; }
+    if (channels != 16 && channels != 32 && channels != 64 && channels != 128) {
+        err = "channels must be one of 16, 32, 64, 128";
+        return DBAZ_EINVAL;
+    }
+    if (blocks < 0 || head_channels < 1 || value_fc < 1 || value_fc > 64) { err = "bad network shape"; return DBAZ_EINVAL; }
+    if (nn->g.A > 256 - value_fc) { err = "A + value_fc must be <= 256"; return DBAZ_EINVAL; }
+    nn_free_device(nn);
+    nn->sd.clear();
+    nn->kind = kind; nn->C = channels; nn->blocks = blocks; nn->hc = head_channels; nn->vf = value_fc;
+    return DBAZ_OK;
+}
+
+int nn_set_tensor(NNState *nn, const char *key, const float *data, int64_t numel, std::string &err)
+{
+    if (nn->kind == 0) { err = "dbaz_nn_configure not called"; return DBAZ_ESTATE; }
+    if (numel < 0) { err = "negative numel"; return DBAZ_EINVAL; }
+    nn->sd[key] = std::vector<float>(data, data + numel);
+    nn->ready = false;
+    return DBAZ_OK;
+}
+
+static const std::vector<float> *sd_get(NNState *nn, const std::string &k, size_t numel, std::string &err)
+{
+    auto it = nn->sd.find(k);
+    if (it == nn->sd.end()) { err = "missing state_dict entry '" + k + "'"; return nullptr; }
+    if (it->second.size() != numel) {
+        err = "state_dict entry '" + k + "' has " + std::to_string(it->second.size()) + " elements, expected " + std::to_string(numel);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+// eval-mode BatchNorm as y = x*s + t  (eps = 1e-5, torch default; nn.py:20,45,47)
+static bool bn_affine(NNState *nn, const std::string &p, int n, std::vector<double> &s, std::vector<double> &t, std::string &err)
+{
+    auto w = sd_get(nn, p + ".weight", n, err); if (!w) return false;
+    auto b = sd_get(nn, p + ".bias", n, err); if (!b) return false;
+    auto m = sd_get(nn, p + ".running_mean", n, err); if (!m) return false;
+    auto v = sd_get(nn, p + ".running_var", n, err); if (!v) return false;
+    s.resize(n); t.resize(n);
+    for (int i = 0; i < n; i++) {
+        s[i] = (double)(*w)[i] / sqrt((double)(*v)[i] + 1e-5);
+        t[i] = (double)(*b)[i] - (double)(*m)[i] * s[i];
+    }
+    return true;
+}
+
+// conv3x3 [C][C][3][3] + following BN -> packed fragment order [C/16][9][C/16][64][4]
+static bool pack_conv(NNState *nn, const std::string &conv, const std::string &bn, int C, ConvLayer &L, std::string &err)
+{
+    auto w = sd_get(nn, conv + ".weight", (size_t)C * C * 9, err); if (!w) return false;
+    auto b = sd_get(nn, conv + ".bias", C, err); if (!b) return false;
+    std::vector<double> s, t;
+    if (!bn_affine(nn, bn, C, s, t, err)) return false;
+    const int KC = C / 16;
+    std::vector<float> pk((size_t)C * C * 9), bias(C);
+    for (int ct = 0; ct < C / 16; ct++)
+        for (int tap = 0; tap < 9; tap++)
+            for (int kc = 0; kc < KC; kc++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 4; e++) {
+                        int co = ct * 16 + (lane & 15), ci = kc * 16 + 4 * (lane >> 4) + e;
+                        double v = (double)(*w)[((size_t)co * C + ci) * 9 + tap] * s[co];
+                        pk[((((size_t)ct * 9 + tap) * KC + kc) * 64 + lane) * 4 + e] = (float)v;
+                    }
+    for (int co = 0; co < C; co++) bias[co] = (float)((double)(*b)[co] * s[co] + t[co]);
+    L.w = nn_upload(nn, pk);
+    L.bias = nn_upload(nn, bias);
+    if (!L.w || !L.bias) { err = "hipMalloc failed (conv weights)"; return false; }
+    return true;
+}
+
+int nn_commit(NNState *nn, hipStream_t s, std::string &err)
+{
+    (void)s;
+    if (nn->kind != DBAZ_EVAL_RESNET) { err = "dbaz_nn_configure not called"; return DBAZ_ESTATE; }
+    const Geo &g = nn->g;
+    const int C = nn->C, hc = nn->hc, vf = nn->vf, HW = g.HW, A = g.A, K = hc * HW;
+    for (void *p : nn->allocs) (void)hipFree(p);
+    nn->allocs.clear();
+    nn->tower.clear();
+    nn->ready = false;
+    // bn_input
+    {
+        std::vector<double> si, ti;
+        if (!bn_affine(nn, "bn_input", 3, si, ti, err)) return DBAZ_EINVAL;
+        std::vector<float> fs(si.begin(), si.end()), ft(ti.begin(), ti.end());
+        nn->in_s = nn_upload(nn, fs);
+        nn->in_t = nn_upload(nn, ft);
+    }
+    // conv0 + bn0 -> [9][3][C]
+    {
+        auto w = sd_get(nn, "resnet.conv0.weight", (size_t)C * 27, err); if (!w) return DBAZ_EINVAL;
+        auto b = sd_get(nn, "resnet.conv0.bias", C, err); if (!b) return DBAZ_EINVAL;
+        std::vector<double> sc, tc;
+        if (!bn_affine(nn, "resnet.bn0", C, sc, tc, err)) return DBAZ_EINVAL;
+        std::vector<float> pk((size_t)27 * C), bias(C);
+        for (int co = 0; co < C; co++) {
+            for (int ci = 0; ci < 3; ci++)
+                for (int tap = 0; tap < 9; tap++)
+                    pk[(size_t)(tap * 3 + ci) * C + co] = (float)((double)(*w)[((size_t)co * 3 + ci) * 9 + tap] * sc[co]);
+            bias[co] = (float)((double)(*b)[co] * sc[co] + tc[co]);
+        }
+        nn->w0 = nn_upload(nn, pk);
+        nn->b0 = nn_upload(nn, bias);
+    }
+    for (int i = 0; i < nn->blocks; i++) {
+        std::string p = "resnet.resblocks." + std::to_string(i);
+        ConvLayer a, b;
+        if (!pack_conv(nn, p + ".conv1", p + ".bn1", C, a, err)) return DBAZ_EINVAL;
+        if (!pack_conv(nn, p + ".conv2", p + ".bn2", C, b, err)) return DBAZ_EINVAL;
+        nn->tower.push_back(a);
+        nn->tower.push_back(b);
+    }
+    // heads: conv1x1 + BN folded, rows [policy hc | value hc]
+    {
+        std::vector<float> hw((size_t)2 * hc * C), hb(2 * hc);
+        const char *heads[2] = {"policy_head", "value_head"};
+        for (int h = 0; h < 2; h++) {
+            std::string p = heads[h];
+            auto w = sd_get(nn, p + ".conv0.weight", (size_t)hc * C, err); if (!w) return DBAZ_EINVAL;
+            auto b = sd_get(nn, p + ".conv0.bias", hc, err); if (!b) return DBAZ_EINVAL;
+            std::vector<double> sc, tc;
+            if (!bn_affine(nn, p + ".bn0", hc, sc, tc, err)) return DBAZ_EINVAL;
+            for (int o = 0; o < hc; o++) {
+                for (int c = 0; c < C; c++) hw[(size_t)(h * hc + o) * C + c] = (float)((double)(*w)[(size_t)o * C + c] * sc[o]);
+                hb[h * hc + o] = (float)((double)(*b)[o] * sc[o] + tc[o]);
+            }
+        }
+        nn->hw = nn_upload(nn, hw);
+        nn->hb = nn_upload(nn, hb);
+        auto wp = sd_get(nn, "policy_head.fc.weight", (size_t)A * K, err); if (!wp) return DBAZ_EINVAL;
+        auto bp = sd_get(nn, "policy_head.fc.bias", A, err); if (!bp) return DBAZ_EINVAL;
+        std::vector<float> wpt((size_t)K * A);
+        for (int a = 0; a < A; a++) for (int k = 0; k < K; k++) wpt[(size_t)k * A + a] = (*wp)[(size_t)a * K + k];
+        nn->wp = nn_upload(nn, wpt);
+        nn->bp = nn_upload(nn, *bp);
+        auto w0 = sd_get(nn, "value_head.fc0.weight", (size_t)vf * K, err); if (!w0) return DBAZ_EINVAL;
+        auto b0 = sd_get(nn, "value_head.fc0.bias", vf, err); if (!b0) return DBAZ_EINVAL;
+        auto w1 = sd_get(nn, "value_head.fc1.weight", vf, err); if (!w1) return DBAZ_EINVAL;
+        auto b1 = sd_get(nn, "value_head.fc1.bias", 1, err); if (!b1) return DBAZ_EINVAL;
+        std::vector<float> w0t((size_t)K * vf);
+        for (int u = 0; u < vf; u++) for (int k = 0; k < K; k++) w0t[(size_t)k * vf + u] = (*w0)[(size_t)u * K + k];
+        nn->wv0 = nn_upload(nn, w0t);
+        nn->bv0 = nn_upload(nn, *b0);
+        nn->wv1 = nn_upload(nn, *w1);
+        nn->bv1 = nn_upload(nn, *b1);
+    }
+    const size_t act = (size_t)nn->max_batch * HW * C;
+    nn->actA = nn_alloc<float>(nn, act);
+    nn->actB = nn_alloc<float>(nn, act);
+    nn->actC = nn_alloc<float>(nn, act);
+    nn->hact = nn_alloc<float>(nn, (size_t)nn->max_batch * 2 * K);
+    if (!nn->actA || !nn->actB || !nn->actC || !nn->hact || !nn->wv1 || !nn->w0) { err = "hipMalloc failed (network buffers)"; return DBAZ_EDEVICE; }
+    // conv workgroup geometry: S whole samples, NT position tiles of 16 rows (<= MAXT)
+    const size_t lds_budget = 150 * 1024;
+    int S = (16 * MAXT) / HW;
+    if (S < 1) S = 1;
+    while (S > 1 && (size_t)(S * HW + 1) * (C + 8) * 4 > lds_budget) S--;
+    nn->S = S;
+    nn->NT = (S * HW + 15) / 16;
+    if (nn->NT > MAXT) { err = "board too large for the conv tile"; return DBAZ_EINVAL; }
+    nn->conv_lds = (size_t)(S * HW + 1) * (C + 8) * 4;
+    hipError_t he = hipSuccess;
+    const int lds_i = (int)nn->conv_lds;
+    switch (C) {
+    case 16: he = hipFuncSetAttribute((const void *)k_conv3x3<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_i); break;
+    case 32: he = hipFuncSetAttribute((const void *)k_conv3x3<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_i); break;
+    case 64: he = hipFuncSetAttribute((const void *)k_conv3x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_i); break;
+    case 128: he = hipFuncSetAttribute((const void *)k_conv3x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_i); break;
+    }
+    if (he != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); return DBAZ_EDEVICE; }
+    size_t hl = ((size_t)2 * hc * (C + 1) + (size_t)HW * (C + 1)) * 4;
+    if (hl > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_head_conv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl);
+    nn->ready = true;
+    return DBAZ_OK;
+}
+
+static void launch_conv(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, const ConvLayer &L,
+                        const float *res, float *out, int flags)
+{
+    const int grid = (max_n + nn->S - 1) / nn->S;
+    switch (nn->C) {
+    case 16: hipLaunchKernelGGL(k_conv3x3<16>, dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->NT, n_dev, in, L.w, L.bias, res, L.post_s, L.post_t, out, flags); break;
+    case 32: hipLaunchKernelGGL(k_conv3x3<32>, dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->NT, n_dev, in, L.w, L.bias, res, L.post_s, L.post_t, out, flags); break;
+    case 64: hipLaunchKernelGGL(k_conv3x3<64>, dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->NT, n_dev, in, L.w, L.bias, res, L.post_s, L.post_t, out, flags); break;
+    case 128: hipLaunchKernelGGL(k_conv3x3<128>, dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->NT, n_dev, in, L.w, L.bias, res, L.post_s, L.post_t, out, flags); break;
+    }
+}
+
+void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *list_dev, const int32_t *n_dev, int max_n,
+                float *P, float *V, int AS, hipEvent_t ev_begin, hipEvent_t ev_end)
+{
+    const Geo &g = nn->g;
+    const int C = nn->C, hc = nn->hc, HW = g.HW;
+    if (max_n > nn->max_batch) max_n = nn->max_batch;
+    size_t l0 = ((size_t)3 * (g.H + 2) * (g.W + 2) + (size_t)27 * C) * 4;
+    hipLaunchKernelGGL(k_conv0, dim3(max_n), dim3(256), l0, s, g, C, feat, list_dev, n_dev, nn->in_s, nn->in_t, nn->w0, nn->b0, nn->actA);
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    float *x = nn->actA, *y = nn->actB, *z = nn->actC;
+    for (int b = 0; b < nn->blocks; b++) {
+        launch_conv(nn, s, n_dev, max_n, x, nn->tower[2 * b], nullptr, y, 2);      // relu(bn1(conv1(x)))
+        launch_conv(nn, s, n_dev, max_n, y, nn->tower[2 * b + 1], x, z, 1 | 2);    // relu(bn2(conv2(y)) + x)
+        float *t = x; x = z; z = t;
+    }
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+    size_t hl = ((size_t)2 * hc * (C + 1) + (size_t)HW * (C + 1)) * 4;
+    hipLaunchKernelGGL(k_head_conv, dim3(max_n), dim3(256), hl, s, g, C, hc, n_dev, x, nn->hw, nn->hb, nn->hact);
+    size_t fl = ((size_t)2 * hc * HW + 256 + 64) * 4;
+    hipLaunchKernelGGL(k_head_fc, dim3(max_n), dim3(256), fl, s, g, hc, nn->vf, AS, list_dev, n_dev, nn->hact, nn->wp, nn->bp,
+                       nn->wv0, nn->bv0, nn->wv1, nn->bv1, P, V);
+}
+
+double nn_flops_per_sample(const NNState *nn)
+{
+    // 2*MAC of conv + FC layers: conv0, 2*blocks tower convs, head convs, FCs
+    const Geo &g = nn->g;
+    const double HW = g.HW, C = nn->C, hc = nn->hc, K = hc * HW;
+    double f = 2.0 * HW * 27 * C + 2.0 * nn->blocks * 2.0 * HW * 9 * C * C;
+    f += 2.0 * 2.0 * HW * C * hc + 2.0 * K * g.A + 2.0 * K * nn->vf + 2.0 * nn->vf;
+    return f;
+}
+
+const char *nn_tower_kernel_name(const NNState *nn) { (void)nn; return "k_conv3x3"; }

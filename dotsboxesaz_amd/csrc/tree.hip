@@ -1,0 +1,1205 @@
+// tree.hip -- per-simulation MCTS kernels, one 64-lane wavefront per game.
+//
+// Restates the reference's sequential PUCT search (mcts.py, max_pending_evals = 1):
+//   k_select          select_leaf      mcts.py:105-114  (+ children_ucb_score/best_child :91-103,
+//                                                           lazy child creation utils/utils.py:51-58)
+//   k_expand_backup   _search tail     mcts.py:186-199  (prior masking, expand :116-119, backup :121-132)
+//   root_prep         UCT_search       mcts.py:211-226  (root renormalisation + Dirichlet mix)
+//   k_search_begin    UCT_search       mcts.py:205-208
+//   k_advance         init_mcts_tree   mcts.py:163-180  + SelfPlay.play_game / get_next_move /
+//                                      get_datasets rows (self_play.py:27-35, 51-74, 95-156)
+//
+// Numerics follow numpy (NEP 50) exactly: UCB in float64, statistics in float32/int32,
+// float32 prior sums with numpy's pairwise summation.  This TU is compiled with
+// -ffp-contract=off: a fused multiply-add would change the roundings.
+#include "rules.h"
+#include "tree.h"
+
+// ------------------------------------------------------------------------------------
+// node access
+// ------------------------------------------------------------------------------------
+struct NodeMeta {
+    GState st;
+    int parent, move, flags, result, deepness;
+};
+
+__device__ __forceinline__ uint32_t *node_ptr(uint32_t *pool, const Geo &g, int idx)
+{
+    return pool + (size_t)idx * g.node_dw;
+}
+
+__device__ __forceinline__ NodeMeta load_meta(uint32_t *pool, const Geo &g, int idx)
+{
+    const uint32_t *nd = node_ptr(pool, g, idx);
+    const uint4 a = *reinterpret_cast<const uint4 *>(nd);
+    const uint4 b = *reinterpret_cast<const uint4 *>(nd + 4);
+    const uint4 c = *reinterpret_cast<const uint4 *>(nd + 8);
+    NodeMeta m;
+    m.st.e0 = (uint64_t)a.x | ((uint64_t)a.y << 32);
+    m.st.e1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    m.st.e2 = (uint64_t)b.x | ((uint64_t)b.y << 32);
+    m.st.e3 = (uint64_t)b.z | ((uint64_t)b.w << 32);
+    m.parent = (int)c.x;
+    m.move = (int)(int16_t)(c.y & 0xFFFFu);
+    m.st.to_play = (int)((c.y >> 16) & 0xFFu);
+    m.st.just_played = (int)((c.y >> 24) & 0xFFu) - 1;
+    m.st.b2c0 = (int)(int16_t)(c.z & 0xFFFFu);
+    m.st.b2c1 = (int)(int16_t)(c.z >> 16);
+    m.flags = (int)(c.w & 0xFFu);
+    m.result = (int)((c.w >> 8) & 0xFFu) - 1;
+    m.deepness = (int)(c.w >> 16);
+    return m;
+}
+
+__device__ __forceinline__ uint32_t pack_dw9(int move, int to_play, int just_played)
+{
+    return ((uint32_t)(uint16_t)(int16_t)move) | ((uint32_t)(to_play & 0xFF) << 16) |
+           ((uint32_t)((just_played + 1) & 0xFF) << 24);
+}
+__device__ __forceinline__ uint32_t pack_dw10(int b0, int b1)
+{
+    return ((uint32_t)(uint16_t)(int16_t)b0) | ((uint32_t)(uint16_t)(int16_t)b1 << 16);
+}
+__device__ __forceinline__ uint32_t pack_dw11(int flags, int result, int deepness)
+{
+    return (uint32_t)(flags & 0xFF) | ((uint32_t)((result + 1) & 0xFF) << 8) | ((uint32_t)deepness << 16);
+}
+
+// UCTNode.__init__ (mcts.py:47-65): zeroed W / visits, no children; P is written at expand.
+__device__ void init_node(uint32_t *pool, const Geo &g, int idx, const GState &st, int parent, int move,
+                          int deepness, int lane)
+{
+    uint32_t *nd = node_ptr(pool, g, idx);
+    int res = gs_result(st);
+    int flags = (res != DBAZ_RESULT_NONE) ? NF_TERMINAL : 0;
+    if (lane < META_DW) {
+        uint32_t v = 0;
+        switch (lane) {
+        case 0: v = (uint32_t)st.e0; break;
+        case 1: v = (uint32_t)(st.e0 >> 32); break;
+        case 2: v = (uint32_t)st.e1; break;
+        case 3: v = (uint32_t)(st.e1 >> 32); break;
+        case 4: v = (uint32_t)st.e2; break;
+        case 5: v = (uint32_t)(st.e2 >> 32); break;
+        case 6: v = (uint32_t)st.e3; break;
+        case 7: v = (uint32_t)(st.e3 >> 32); break;
+        case 8: v = (uint32_t)parent; break;
+        case 9: v = pack_dw9(move, st.to_play, st.just_played); break;
+        case 10: v = pack_dw10(st.b2c0, st.b2c1); break;
+        case 11: v = pack_dw11(flags, res, deepness); break;
+        default: v = 0; break;
+        }
+        nd[lane] = v;
+    }
+    uint32_t *rows = nd + META_DW;
+    for (int i = lane; i < g.AS; i += WAVE) {
+        rows[g.AS + i] = 0u;             // W = 0.0f
+        rows[2 * g.AS + i] = 0u;         // visits = 0
+        rows[3 * g.AS + i] = 0xFFFFFFFFu; // child = -1
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// numpy pairwise summation on LDS data (<= 256 elements), result broadcast to the wave.
+// Mirrors @TYPE@_pairwise_sum (numpy loops_utils.h.src): 8 strided accumulators per
+// block of <= 128, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), tail added in order.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__device__ T np_pairwise_sum(const T *a, int n, int lane)
+{
+    int grp = lane >> 3, j = lane & 7;
+    int s = 0, L = n;
+    int n2 = 0;
+    if (n > 128) {
+        n2 = n / 2;
+        n2 -= n2 % 8;
+        if (grp == 0) { s = 0; L = n2; } else { s = n2; L = n - n2; }
+    }
+    T res;
+    if (L < 8) {
+        res = (T)(-0.0);
+        for (int i = 0; i < L; i++)
+            res += a[s + i];
+    } else {
+        T r = a[s + j];
+        int lim = L - (L % 8);
+        for (int i = 8; i < lim; i += 8)
+            r += a[s + i + j];
+        T t = r + __shfl_down(r, 1);
+        T u = t + __shfl_down(t, 2);
+        res = u + __shfl_down(u, 4);
+        for (int i = lim; i < L; i++)
+            res += a[s + i];
+    }
+    T b0 = __shfl(res, 0);
+    if (n > 128) {
+        T b1 = __shfl(res, 8);
+        return b0 + b1;
+    }
+    return b0;
+}
+
+// ------------------------------------------------------------------------------------
+// formula evaluators (restated from oracle ob_eval_formula; a pure function of the hash)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t fmix64(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t formula_hash(const GState &st)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ULL;
+    h = fmix64(h ^ st.e0);
+    h = fmix64(h ^ st.e1);
+    h = fmix64(h ^ st.e2);
+    h = fmix64(h ^ st.e3);
+    int b = st.to_play == 0 ? st.b2c0 : st.b2c1;
+    h = fmix64(h ^ (uint64_t)(int64_t)(b + 512));
+    return h;
+}
+__device__ __forceinline__ float formula_p(uint64_t h, int i, int kind)
+{
+    if (kind == DBAZ_EVAL_FORMULA_UNIFORM)
+        return 1.0f;
+    uint64_t t = fmix64(h + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ULL);
+    uint32_t u = (uint32_t)(t >> 20) & 0xFFFFu;
+    return (float)((u & 0xFFu) + 1u) * (float)(((u >> 8) & 0xFFu) + 1u);
+}
+__device__ __forceinline__ float formula_v(uint64_t h, int kind)
+{
+    if (kind == DBAZ_EVAL_FORMULA_UNIFORM)
+        return 0.0f;
+    uint64_t t = fmix64(h ^ 0xD6E8FEB86659FD93ULL);
+    uint32_t u = (uint32_t)(t >> 17) & 0xFFFFu;
+    return ((float)u - 32768.0f) / 32768.0f;
+}
+
+// ------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (production move sampling / Dirichlet noise; the reference
+// uses numpy's global MT19937, which parity tests replace by injected draws)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox(uint4 c, uint2 k)
+{
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ double u01(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+// stream: (game, ply, element, purpose)
+__device__ double rng_gamma(uint64_t seed, uint64_t game, uint32_t ply, uint32_t elem, double a)
+{
+    uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+    double boost = 1.0;
+    uint32_t ctr = 0;
+    if (a < 1.0) {
+        uint4 r = philox(make_uint4((uint32_t)game, (uint32_t)(game >> 32) ^ (ply << 8), elem, 0x40000000u), key);
+        double u = u01(r.x, r.y);
+        if (u < 1e-300) u = 1e-300;
+        boost = pow(u, 1.0 / a);
+        a += 1.0;
+    }
+    double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;; ctr++) {
+        uint4 r = philox(make_uint4((uint32_t)game, (uint32_t)(game >> 32) ^ (ply << 8), elem, 0x80000000u + ctr), key);
+        double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
+        if (u1 < 1e-300) u1 = 1e-300;
+        double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        uint4 r2 = philox(make_uint4((uint32_t)game, (uint32_t)(game >> 32) ^ (ply << 8), elem, 0xC0000000u + ctr), key);
+        double u = u01(r2.x, r2.y);
+        if (u < 1.0 - 0.0331 * x * x * x * x || (u > 0 && log(u) < 0.5 * x * x + d * (1.0 - v + log(v))))
+            return d * v * boost;
+        if (ctr > 64) return d * boost; // unreachable in practice; bounded loop
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// root prior renormalisation + Dirichlet mix, mcts.py:211-226 (wave-cooperative)
+// ------------------------------------------------------------------------------------
+__device__ void root_prep(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, Slot *S,
+                          uint32_t *pool, float *ldsf, double *ldsd, int lane)
+{
+    NodeMeta rm = load_meta(pool, g, 0);
+    const float *Prow = reinterpret_cast<const float *>(node_ptr(pool, g, 0) + META_DW);
+    double *rp = B.root_prior + (size_t)slot * g.AS;
+    const int A = g.A;
+    int prepped = S->root_prepped, isf64 = S->root_prior_f64;
+    bool probs_f64;
+    __syncthreads();
+    if (!prepped || !isf64) {
+        for (int i = lane; i < A; i += WAVE)
+            ldsf[i] = prepped ? (float)rp[i] : Prow[i];
+        __syncthreads();
+        float cpsum = np_pairwise_sum<float>(ldsf, A, lane);
+        probs_f64 = !(cpsum != 0.0f);
+        __syncthreads();
+        for (int i = lane; i < A; i += WAVE) {
+            if (!probs_f64) ldsf[i] = ldsf[i] / cpsum; else ldsd[i] = 0.0;
+        }
+    } else {
+        for (int i = lane; i < A; i += WAVE)
+            ldsd[i] = rp[i];
+        __syncthreads();
+        double cpsum = np_pairwise_sum<double>(ldsd, A, lane);
+        probs_f64 = true;
+        __syncthreads();
+        for (int i = lane; i < A; i += WAVE)
+            ldsd[i] = (cpsum != 0.0) ? ldsd[i] / cpsum : 0.0;
+    }
+    __syncthreads();
+    const double onemc = 1.0 - cfg.coeff;
+    if (cfg.alpha > 0) {
+        const bool ext = B.noise_valid[slot] != 0;
+        const double *nin = B.noise_in + (size_t)slot * g.AS;
+        double gsum = 0.0;
+        double gam[4] = {0, 0, 0, 0};
+        if (!ext) {
+            // np.random.dirichlet over ALL A slots (mcts.py:220-222), own Philox stream
+            int k = 0;
+            for (int i = lane; i < A; i += WAVE, k++) {
+                gam[k] = rng_gamma(cfg.seed, (uint64_t)S->game_idx, (uint32_t)S->move_idx, (uint32_t)i, cfg.alpha);
+                gsum += gam[k];
+            }
+            for (int o = 32; o > 0; o >>= 1)
+                gsum += __shfl_xor(gsum, o);
+        }
+        int k = 0;
+        for (int i = lane; i < A; i += WAVE, k++) {
+            double nz = ext ? nin[i] : gam[k] / gsum;
+            nz = nz * (gs_valid(g, rm.st, i) ? 1.0 : 0.0);
+            double a = probs_f64 ? onemc * ldsd[i] : (double)((float)onemc * ldsf[i]);
+            rp[i] = a + cfg.coeff * nz;
+        }
+        S->root_prior_f64 = 1;
+        if (lane == 0) B.noise_valid[slot] = 0;
+    } else {
+        const double cn = cfg.coeff * 0.0;
+        for (int i = lane; i < A; i += WAVE)
+            rp[i] = probs_f64 ? onemc * ldsd[i] + cn : (double)((float)onemc * ldsf[i] + (float)cn);
+        S->root_prior_f64 = probs_f64 ? 1 : 0;
+    }
+    S->root_prepped = 1;
+    __syncthreads();
+}
+
+__device__ __forceinline__ int rule_num_reads(const Geo &g, const SearchCfg &cfg, const GState &st)
+{
+    // n_searches = min(4*factorial(nb_valid_moves), mcts_num_read), self_play.py:64-65
+    int nb = gs_count_valid(g, st);
+    double f = 4.0;
+    for (int i = 2; i <= nb; i++) {
+        f *= (double)i;
+        if (f > (double)cfg.mcts_num_read) break;
+    }
+    return f < (double)cfg.mcts_num_read ? (int)f : cfg.mcts_num_read;
+}
+
+// UCT_search prologue (mcts.py:205-226) for one slot; num_reads < 0 = driver rule
+__device__ void begin_search(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, Slot *S,
+                             uint32_t *pool, int num_reads, float *ldsf, double *ldsd, int lane)
+{
+    NodeMeta rm = load_meta(pool, g, 0);
+    if (rm.flags & NF_TERMINAL) { // play_game never searches a terminal root
+        S->phase = PH_IDLE;
+        S->sims_left = 0;
+        return;
+    }
+    if (num_reads < 0)
+        num_reads = rule_num_reads(g, cfg, rm.st);
+    S->sims_left = num_reads;
+    if (rm.flags & NF_EXPANDED) {
+        root_prep(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
+        S->phase = num_reads > 0 ? PH_SIMS : PH_READY;
+    } else {
+        S->phase = PH_EXPAND_ROOT;
+    }
+}
+
+__global__ void __launch_bounds__(WAVE) k_search_begin(Geo g, SearchCfg cfg, TreeBufs B, const int32_t *num_reads)
+{
+    __shared__ float ldsf[DBAZ_MAX_A];
+    __shared__ double ldsd[DBAZ_MAX_A];
+    int slot = blockIdx.x, lane = threadIdx.x;
+    Slot *S = B.slots + slot;
+    if (S->phase == PH_ERROR || S->game_idx < 0)
+        return;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    begin_search(g, cfg, B, slot, S, pool, num_reads ? num_reads[slot] : -1, ldsf, ldsd, lane);
+}
+
+// ------------------------------------------------------------------------------------
+// select_leaf, mcts.py:105-114
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cand_beats(double xa, int ia, bool ha, double xb, int ib, bool hb)
+{
+    // numpy argmax order: first maximum; the first NaN beats everything
+    if (!ha) return false;
+    if (!hb) return true;
+    bool na = xa != xa, nb = xb != xb;
+    if (na || nb) {
+        if (na && nb) return ia < ib;
+        return na;
+    }
+    return xa > xb || (xa == xb && ia < ib);
+}
+
+__global__ void __launch_bounds__(WAVE) k_select(Geo g, SearchCfg cfg, TreeBufs B)
+{
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    Slot *S = B.slots + slot;
+    const int phase = S->phase;
+    if (phase != PH_EXPAND_ROOT && phase != PH_SIMS)
+        return;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    PathEnt *path = B.path + (size_t)slot * g.dmax;
+    const double *rprior = B.root_prior + (size_t)slot * g.AS;
+    const int A = g.A;
+
+    int cur = 0, depth = 0, in_move = -1;
+    int n_nodes = S->n_nodes;
+    int Nself = S->root_N;
+    NodeMeta m = load_meta(pool, g, 0);
+    in_move = m.move;
+    if ((m.flags & NF_EXPANDED) && !(m.flags & NF_TERMINAL)) {
+        if (lane == 0)
+            S->root_W = S->root_W - 1.0f; // current.total_value -= VIRTUAL_LOSS (root slot)
+    }
+    int err = 0;
+    while ((m.flags & NF_EXPANDED) && !(m.flags & NF_TERMINAL)) {
+        uint32_t *nd = node_ptr(pool, g, cur);
+        const float *Prow = reinterpret_cast<const float *>(nd + META_DW);
+        float *Wrow = reinterpret_cast<float *>(nd + META_DW + g.AS);
+        uint32_t *NSrow = nd + META_DW + 2 * g.AS;
+        int32_t *Crow = reinterpret_cast<int32_t *>(nd + META_DW + 3 * g.AS);
+        // children_ucb_score, mcts.py:91-99 (float64 throughout)
+        double pbc0, sq;
+        if (Nself < cfg.table_n) {
+            pbc0 = B.pbc_table[Nself];
+            sq = B.sqrt_table[Nself];
+        } else {
+            pbc0 = log(((double)Nself + cfg.cpuct_base + 1.0) / cfg.cpuct_base) + cfg.cpuct;
+            sq = sqrt((double)Nself);
+        }
+        double bx = 0.0;
+        int bi = 0x7fffffff;
+        float bw = 0.0f;
+        uint32_t bns = 0;
+        bool have = false;
+        for (int i = lane; i < A; i += WAVE) {
+            double P = (cur == 0) ? rprior[i] : (double)Prow[i];
+            float w = Wrow[i];
+            uint32_t ns = NSrow[i];
+            int n = (int)(ns & NS_MASK);
+            double sgn = (ns & NS_SAME) ? 1.0 : -1.0;
+            double t = sq / (double)(n + 1);
+            double pb_c = pbc0 * t;
+            double prior_score = pb_c * P;
+            double value_score = (double)w / (double)(1 + n);
+            value_score = value_score * sgn;
+            double score = prior_score + value_score;
+            double inval = gs_valid(g, m.st, i) ? 0.0 : 1.0;
+            double x = -1e12 * inval + score; // best_child, mcts.py:101-103
+            bool take;
+            if (!have) take = true;
+            else if (bx != bx) take = false;
+            else take = !(x <= bx);
+            if (take) { bx = x; bi = i; bw = w; bns = ns; have = true; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            double ox = __shfl_xor(bx, o);
+            int oi = __shfl_xor(bi, o);
+            int oh = __shfl_xor((int)have, o);
+            if (cand_beats(ox, oi, oh != 0, bx, bi, have)) { bx = ox; bi = oi; have = true; }
+        }
+        const int owner = bi & (WAVE - 1);
+        bw = __shfl(bw, owner);
+        bns = __shfl(bns, owner);
+
+        int child = Crow[bi];
+        if (lane == 0) {
+            PathEnt pe;
+            pe.node = cur; pe.move_in = (int16_t)in_move; pe.to_play = (int16_t)m.st.to_play;
+            path[depth] = pe;
+        }
+        depth++;
+        if (child < 0) {
+            // DictWithDefault.__missing__ -> UCTNode(game_state.play(move)), mcts.py:53-54
+            if (n_nodes >= g.cap) { err = DBAZ_EPOOL; depth--; break; }
+            child = n_nodes++;
+            GState st = m.st;
+            int r = gs_play(g, st, bi, nullptr);
+            if (r < 0) { err = DBAZ_EILLEGAL; depth--; break; }
+            bool same = (st.to_play == st.just_played);
+            if (lane == 0) {
+                Crow[bi] = child;
+                NSrow[bi] = same ? NS_SAME : 0u; // child_player_changed slot (mcts.py:119), visits = 0
+            }
+            init_node(pool, g, child, st, cur, bi, m.deepness + 1, lane);
+            NodeMeta cm;
+            cm.st = st; cm.parent = cur; cm.move = bi;
+            cm.result = gs_result(st);
+            cm.flags = (cm.result != DBAZ_RESULT_NONE) ? NF_TERMINAL : 0;
+            cm.deepness = m.deepness + 1;
+            cur = child; in_move = bi; m = cm;
+            break;
+        }
+        NodeMeta cm = load_meta(pool, g, child);
+        if ((cm.flags & NF_EXPANDED) && !(cm.flags & NF_TERMINAL)) {
+            if (lane == owner)
+                Wrow[bi] = bw - 1.0f; // VIRTUAL_LOSS on the node being left next iteration
+            Nself = (int)(bns & NS_MASK);
+        }
+        cur = child; in_move = bi; m = cm;
+    }
+    if (err) {
+        if (lane == 0) { S->error = err; S->phase = PH_ERROR; }
+        return;
+    }
+    if (lane == 0) {
+        PathEnt pe;
+        pe.node = cur; pe.move_in = (int16_t)in_move; pe.to_play = (int16_t)m.st.to_play;
+        path[depth] = pe;
+        S->leaf = cur;
+        S->path_len = depth + 1;
+        S->leaf_terminal = (m.flags & NF_TERMINAL) ? 1 : 0;
+        S->leaf_result = m.result;
+        S->leaf_to_play = m.st.to_play;
+        S->n_nodes = n_nodes;
+        if (n_nodes > S->pool_high) S->pool_high = n_nodes;
+    }
+    if (!(m.flags & NF_TERMINAL)) {
+        // get_features of the leaf as float32 planes (nn_batch_builder + nn.py:157)
+        float *f = B.feat + (size_t)slot * 3 * g.HW;
+        for (int i = lane; i < 3 * g.HW; i += WAVE)
+            f[i] = (float)gs_feature(g, m.st, i);
+        if (lane == 0 && (cfg.evaluator == DBAZ_EVAL_RESNET || cfg.evaluator == DBAZ_EVAL_SIMPLENN)) {
+            int j = atomicAdd(B.n_eval, 1);
+            B.eval_list[j] = slot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// _search tail: prior masking (mcts.py:189-196), expand (:116-119), backup (:121-132)
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, TreeBufs B)
+{
+    __shared__ float ldsf[DBAZ_MAX_A];
+    __shared__ double ldsd[DBAZ_MAX_A];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    Slot *S = B.slots + slot;
+    const int phase = S->phase;
+    if (phase != PH_EXPAND_ROOT && phase != PH_SIMS)
+        return;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    const PathEnt *path = B.path + (size_t)slot * g.dmax;
+    const int A = g.A;
+    const int leaf = S->leaf, plen = S->path_len;
+    NodeMeta lm = load_meta(pool, g, leaf);
+    uint32_t *nd = node_ptr(pool, g, leaf);
+    float v;
+    if (!(lm.flags & NF_TERMINAL)) {
+        float *Prow = reinterpret_cast<float *>(nd + META_DW);
+        uint64_t h = 0;
+        const bool formula = cfg.evaluator == DBAZ_EVAL_FORMULA_HASH || cfg.evaluator == DBAZ_EVAL_FORMULA_UNIFORM;
+        if (formula) h = formula_hash(lm.st);
+        const float *ep = B.evalP + (size_t)slot * g.AS;
+        for (int i = lane; i < A; i += WAVE) {
+            float p = formula ? formula_p(h, i, cfg.evaluator) : ep[i];
+            ldsf[i] = p * (gs_valid(g, lm.st, i) ? 1.0f : 0.0f); // child_priors * valid
+        }
+        __syncthreads();
+        float s = np_pairwise_sum<float>(ldsf, A, lane);
+        const bool renorm = (s > 0.0f) && (s != 1.0f);
+        for (int i = lane; i < A; i += WAVE)
+            Prow[i] = renorm ? ldsf[i] / s : ldsf[i];
+        v = formula ? formula_v(h, cfg.evaluator) : B.evalV[slot];
+    } else {
+        v = (float)lm.result; // get_result(), python int
+    }
+    if (lane == 0)
+        nd[11] = pack_dw11(lm.flags | NF_EXPANDED, lm.result, lm.deepness);
+    // backup: every path node (root ... leaf) gets W += v_n + VIRTUAL_LOSS, N += 1
+    const int tp = lm.st.to_play;
+    for (int d = lane; d < plen; d += WAVE) {
+        PathEnt pe = path[d];
+        float vn = (pe.to_play == tp) ? v : -v;
+        float add = vn + 1.0f;
+        if (d == 0) {
+            S->root_W = S->root_W + add;
+            S->root_N = S->root_N + 1;
+        } else {
+            uint32_t *pn = node_ptr(pool, g, path[d - 1].node);
+            float *Wr = reinterpret_cast<float *>(pn + META_DW + g.AS);
+            uint32_t *NSr = pn + META_DW + 2 * g.AS;
+            Wr[pe.move_in] = Wr[pe.move_in] + add;
+            NSr[pe.move_in] = NSr[pe.move_in] + 1u;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        const int term = (lm.flags & NF_TERMINAL) ? 1 : 0;
+        S->terminal_count += term;
+        if (lm.deepness > S->max_deepness) S->max_deepness = lm.deepness;
+        S->n_search += 1;
+        S->sum_path += plen;
+        S->n_term += term;
+        S->n_eval += 1 - term;
+    }
+    if (phase == PH_EXPAND_ROOT) {
+        root_prep(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
+        if (lane == 0) S->phase = S->sims_left > 0 ? PH_SIMS : PH_READY;
+    } else if (lane == 0) {
+        int left = S->sims_left - 1;
+        S->sims_left = left;
+        if (left <= 0) S->phase = PH_READY;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// init_mcts_tree (mcts.py:163-180): re-root with in-place subtree compaction
+// ------------------------------------------------------------------------------------
+// Keeps the subtree below `newroot`, sliding kept nodes down in index order (children are
+// always created after their parent, so index order is a topological order and a kept
+// node never moves past an unmoved kept node).  Returns the number of kept nodes.
+__device__ int compact_subtree(const Geo &g, uint32_t *pool, int32_t *remap, uint64_t *marks /*LDS*/,
+                               int newroot, int n_nodes, int lane)
+{
+    int kept = 0;
+    // pass 1: reachability + new indices
+    for (int base = newroot; base < n_nodes; base += WAVE) {
+        int k = base + lane;
+        bool active = k < n_nodes;
+        int parent = -1;
+        if (active)
+            parent = (int)node_ptr(pool, g, k)[8];
+        bool mk = active && (k == newroot);
+        if (active && parent >= newroot && parent < base) {
+            int rel = parent - newroot;
+            mk = (marks[rel >> 6] >> (rel & 63)) & 1ull;
+        }
+        bool inchunk = active && parent >= base && k != newroot;
+        for (;;) {
+            uint64_t bal = __ballot(mk);
+            bool nm = mk || (inchunk && ((bal >> (parent - base)) & 1ull));
+            uint64_t ch = __ballot(nm != mk);
+            mk = nm;
+            if (!ch) break;
+        }
+        uint64_t bal = __ballot(mk);
+        if (lane == 0)
+            marks[(base - newroot) >> 6] = bal;
+        __syncthreads();
+        int idx = kept + __popcll(bal & ((1ull << lane) - 1ull));
+        if (active)
+            remap[k] = mk ? idx : -1;
+        kept += __popcll(bal);
+    }
+    __syncthreads();
+    __threadfence_block();
+    // pass 2: move kept nodes (ascending), fixing parent and child indices
+    const int ndw = g.node_dw;
+    const int c_lo = META_DW + 3 * g.AS, c_hi = META_DW + 4 * g.AS;
+    for (int base = newroot; base < n_nodes; base += WAVE) {
+        uint64_t bal = marks[(base - newroot) >> 6];
+        while (bal) {
+            int b = __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            int k = base + b;
+            int j = remap[k];
+            const uint32_t *src = node_ptr(pool, g, k);
+            uint32_t *dst = node_ptr(pool, g, j);
+            for (int dw0 = 0; dw0 < ndw; dw0 += 4 * WAVE) {
+                uint32_t v[4];
+                int dws[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int dw = dw0 + u * WAVE + lane;
+                    dws[u] = dw;
+                    v[u] = dw < ndw ? src[dw] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int dw = dws[u];
+                    if (dw < ndw) {
+                        if (dw == 8)
+                            v[u] = (k == newroot) ? 0xFFFFFFFFu : (uint32_t)remap[(int)v[u]];
+                        else if (dw >= c_lo && dw < c_hi && (int)v[u] >= 0)
+                            v[u] = (uint32_t)remap[(int)v[u]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (dws[u] < ndw) dst[dws[u]] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    return kept;
+}
+
+// re-root slot on `move`; returns 0 or an error code.  wave-uniform.
+__device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32_t *pool, int move,
+                      int reuse, uint64_t *marks, int lane)
+{
+    NodeMeta rm = load_meta(pool, g, 0);
+    uint32_t *nd0 = node_ptr(pool, g, 0);
+    if (move < 0 || move >= g.A)
+        return DBAZ_EILLEGAL;
+    int child = (int)nd0[META_DW + 3 * g.AS + move];
+    int carried = (int)(nd0[META_DW + 2 * g.AS + move] & NS_MASK);
+    GState st;
+    int child_deep;
+    if (child >= 0) {
+        NodeMeta cm = load_meta(pool, g, child);
+        st = cm.st;
+        child_deep = cm.deepness;
+    } else {
+        st = rm.st;
+        if (gs_play(g, st, move, nullptr) < 0)
+            return DBAZ_EILLEGAL;
+        child_deep = rm.deepness + 1;
+        carried = 0;
+    }
+    __syncthreads();
+    if (reuse && child >= 0) {
+        int32_t *remap = B.remap + (size_t)slot * g.cap;
+        int kept = compact_subtree(g, pool, remap, marks, child, S->n_nodes, lane);
+        S->n_nodes = kept;
+        S->deepness_correction = child_deep;
+        S->tree_size = carried;
+    } else if (reuse) {
+        // children[move] did not exist: a fresh, unexpanded node becomes the root
+        init_node(pool, g, 0, st, -1, move, child_deep, lane);
+        S->n_nodes = 1;
+        S->deepness_correction = child_deep;
+        S->tree_size = carried;
+    } else {
+        // create_root_uct_node(child.game_state); next_node.move = move
+        init_node(pool, g, 0, st, -1, move, 1, lane);
+        S->n_nodes = 1;
+        S->deepness_correction = 0;
+        S->tree_size = 0;
+    }
+    // new TreeRoot: fresh defaultdict slots and statistics (mcts.py:22-31)
+    S->root_N = 0;
+    S->root_W = 0.0f;
+    S->root_prepped = 0;
+    S->root_prior_f64 = 0;
+    S->max_deepness = 0;
+    S->terminal_count = 0;
+    __syncthreads();
+    return 0;
+}
+
+// reset slot to a fresh game from the empty board (create_root_uct_node(BoxesState()))
+__device__ void fresh_game(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, Slot *S,
+                           uint32_t *pool, long long game_idx, int lane)
+{
+    GState st;
+    gs_init(g, st);
+    int ff = S->ff_plies;
+    int plies = 0;
+    if (ff > 0) {
+        // synthetic mid-game population (benchmark only): uniformly random legal plies
+        uint2 key = make_uint2((uint32_t)cfg.seed ^ 0xA5A5A5A5u, (uint32_t)(cfg.seed >> 32));
+        for (int t = 0; t < ff; t++) {
+            int nb = gs_count_valid(g, st);
+            if (nb <= 1) break;
+            uint4 r = philox(make_uint4((uint32_t)game_idx, (uint32_t)(game_idx >> 32), (uint32_t)t, 0x11111111u), key);
+            int pick = (int)(r.x % (uint32_t)nb);
+            int mv = -1;
+            for (int i = 0; i < g.A; i++) {
+                if (gs_valid(g, st, i)) {
+                    if (pick == 0) { mv = i; break; }
+                    pick--;
+                }
+            }
+            GState trial = st;
+            gs_play(g, trial, mv, nullptr);
+            if (gs_result(trial) != DBAZ_RESULT_NONE) break;
+            st = trial;
+            plies++;
+        }
+        S->ff_plies = 0;
+    }
+    init_node(pool, g, 0, st, -1, -1, 1, lane);
+    S->n_nodes = 1;
+    S->root_N = 0;
+    S->root_W = 0.0f;
+    S->root_prepped = 0;
+    S->root_prior_f64 = 0;
+    S->deepness_correction = 0;
+    S->max_deepness = 0;
+    S->terminal_count = 0;
+    S->tree_size = 0;
+    S->move_idx = 0;
+    S->n_rows = 0;
+    S->game_idx = game_idx;
+    S->temperature = 1.0;
+    S->phase = PH_IDLE;
+    (void)plies;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(WAVE) k_set_positions(Geo g, SearchCfg cfg, TreeBufs B, const int16_t *moves,
+                                                        const int32_t *offsets)
+{
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    Slot *S = B.slots + slot;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    GState st;
+    gs_init(g, st);
+    int err = 0;
+    if (moves && offsets) {
+        for (int i = offsets[slot]; i < offsets[slot + 1]; i++)
+            if (gs_play(g, st, moves[i], nullptr) < 0) { err = DBAZ_EILLEGAL; break; }
+    }
+    S->ff_plies = 0;
+    fresh_game(g, cfg, B, slot, S, pool, slot, lane);
+    init_node(pool, g, 0, st, -1, -1, 1, lane);
+    if (lane == 0) {
+        S->error = err;
+        S->phase = err ? PH_ERROR : PH_IDLE;
+        S->n_search = S->sum_path = S->n_eval = S->n_term = 0;
+        S->pool_high = 1;
+    }
+}
+
+// manual init_mcts_tree on every slot with moves[slot] >= 0
+__global__ void __launch_bounds__(WAVE) k_advance_manual(Geo g, SearchCfg cfg, TreeBufs B, const int32_t *moves,
+                                                         int reuse)
+{
+    extern __shared__ uint64_t marks[];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    Slot *S = B.slots + slot;
+    if (S->phase == PH_ERROR || S->game_idx < 0)
+        return;
+    int mv = moves[slot];
+    if (mv < 0)
+        return;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    int err = reroot(g, B, slot, S, pool, mv, reuse, marks, lane);
+    if (lane == 0) {
+        if (err) { S->error = err; S->phase = PH_ERROR; }
+        else { S->phase = PH_IDLE; S->move_idx += 1; }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// self-play driver: SelfPlay.play_game / get_next_move / get_datasets (self_play.py)
+// ------------------------------------------------------------------------------------
+__device__ bool try_emit(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32_t *pool, int lane)
+{
+    // rows of the finished game -> output buffer, z per row (self_play.py:105-112)
+    NodeMeta rm = load_meta(pool, g, 0); // terminal root
+    const int n = S->n_rows;
+    int base = 0;
+    if (lane == 0) {
+        base = atomicAdd(B.out_count, n);
+        if (base + n > B.max_out) {
+            atomicSub(B.out_count, n);
+            base = -1;
+        }
+    }
+    base = __shfl(base, 0);
+    if (base < 0)
+        return false;
+    const int F = 3 * g.HW, A = g.A, rcap = g.E + 1;
+    const int winner = rm.st.just_played;
+    const int zt = rm.result;
+    for (int r = 0; r < n; r++) {
+        const int16_t *sx = B.row_x + ((size_t)slot * rcap + r) * F;
+        int16_t *dx = B.out_x + (size_t)(base + r) * F;
+        for (int i = lane; i < F; i += WAVE) dx[i] = sx[i];
+        const int32_t *sv = B.row_vis + ((size_t)slot * rcap + r) * A;
+        int32_t *dv = B.out_vis + (size_t)(base + r) * A;
+        for (int i = lane; i < A; i += WAVE) dv[i] = sv[i];
+        if (lane == 0) {
+            RowMeta mm = B.row_meta[(size_t)slot * rcap + r];
+            mm.z = (int8_t)((mm.player == winner) ? zt : -zt);
+            B.out_meta[base + r] = mm;
+        }
+    }
+    if (lane == 0) {
+        atomicAdd((unsigned long long *)B.games_finished, 1ull);
+    }
+    return true;
+}
+
+__device__ void next_game_or_idle(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, Slot *S,
+                                  uint32_t *pool, float *ldsf, double *ldsd, int lane);
+
+__device__ void start_move_search(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, Slot *S,
+                                  uint32_t *pool, float *ldsf, double *ldsd, int lane)
+{
+    // play_game loop head (self_play.py:57-66): temperature schedule, sims budget, search
+    const int i = S->move_idx;
+    for (int k = 0; k < cfg.n_temp; k++)
+        if (cfg.temp_idx[k] == i) S->temperature = cfg.temp_val[k];
+    // teacher-forced Dirichlet vector for this (game, ply), if scripted
+    long long gi = S->game_idx - B.first_game;
+    if (cfg.alpha > 0 && B.script_noise && gi >= 0 && gi < B.n_script && B.script_has_noise[gi] && i <= g.E) {
+        const double *src = B.script_noise + ((size_t)gi * (g.E + 1) + i) * g.A;
+        double *dst = B.noise_in + (size_t)slot * g.AS;
+        for (int k = lane; k < g.A; k += WAVE) dst[k] = src[k];
+        if (lane == 0) B.noise_valid[slot] = 1;
+        __syncthreads();
+        __threadfence_block();
+    }
+    begin_search(g, cfg, B, slot, S, pool, -1, ldsf, ldsd, lane);
+}
+
+__device__ void next_game_or_idle(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, Slot *S,
+                                  uint32_t *pool, float *ldsf, double *ldsd, int lane)
+{
+    long long gidx = 0;
+    if (lane == 0)
+        gidx = (long long)atomicAdd((unsigned long long *)B.next_game, 1ull);
+    gidx = __shfl(gidx, 0);
+    if (gidx >= B.last_game) {
+        S->game_idx = -1;
+        S->phase = PH_IDLE;
+        return;
+    }
+    fresh_game(g, cfg, B, slot, S, pool, gidx, lane);
+    start_move_search(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
+}
+
+__global__ void __launch_bounds__(WAVE) k_selfplay_start(Geo g, SearchCfg cfg, TreeBufs B)
+{
+    __shared__ float ldsf[DBAZ_MAX_A];
+    __shared__ double ldsd[DBAZ_MAX_A];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    Slot *S = B.slots + slot;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    if (lane == 0) {
+        S->error = 0;
+        S->n_search = S->sum_path = S->n_eval = S->n_term = 0;
+        S->pool_high = 1;
+    }
+    // deterministic initial assignment: slot i takes game first+i (the dispenser starts behind them)
+    long long gidx = B.first_game + slot;
+    if (gidx >= B.last_game) {
+        S->game_idx = -1;
+        S->phase = PH_IDLE;
+        return;
+    }
+    fresh_game(g, cfg, B, slot, S, pool, gidx, lane);
+    start_move_search(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
+}
+
+// One pass of the driver for every slot whose reads are done (PH_READY) or whose finished
+// game still waits for output space (PH_EMIT).
+__global__ void __launch_bounds__(WAVE) k_advance_auto(Geo g, SearchCfg cfg, TreeBufs B)
+{
+    __shared__ float ldsf[DBAZ_MAX_A];
+    __shared__ double ldsd[DBAZ_MAX_A];
+    extern __shared__ uint64_t marks[];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    Slot *S = B.slots + slot;
+    const int phase = S->phase;
+    if (phase != PH_READY && phase != PH_EMIT)
+        return;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    const int A = g.A, F = 3 * g.HW, rcap = g.E + 1;
+    if (phase == PH_EMIT) {
+        if (try_emit(g, B, slot, S, pool, lane))
+            next_game_or_idle(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
+        return;
+    }
+    NodeMeta rm = load_meta(pool, g, 0);
+    const uint32_t *NS0 = node_ptr(pool, g, 0) + META_DW + 2 * g.AS;
+    // ---- get_next_move (self_play.py:27-35) ----
+    int vmax = 0;
+    long long vsum = 0;
+    for (int i = lane; i < A; i += WAVE) {
+        int vc = (int)(NS0[i] & NS_MASK);
+        vmax = vc > vmax ? vc : vmax;
+        vsum += vc;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        int ov = __shfl_xor(vmax, o);
+        vmax = ov > vmax ? ov : vmax;
+        vsum += __shfl_xor(vsum, o);
+    }
+    int mv = -1;
+    const int ply = S->move_idx;
+    long long gi = S->game_idx - B.first_game;
+    if (B.script_moves && gi >= 0 && gi < B.n_script && ply <= g.E)
+        mv = B.script_moves[(size_t)gi * (g.E + 1) + ply];
+    if (mv < 0) {
+        // probs = (vc/vc.max())**(1/T); probs /= probs.sum(); np.random.choice(A, p=probs)
+        const double invT = 1.0 / S->temperature;
+        for (int i = lane; i < A; i += WAVE) {
+            int vc = (int)(NS0[i] & NS_MASK);
+            ldsd[i] = pow((double)vc / (double)vmax, invT);
+        }
+        __syncthreads();
+        double ps = np_pairwise_sum<double>(ldsd, A, lane);
+        __syncthreads();
+        if (lane == 0) {
+            double c = 0.0;
+            for (int i = 0; i < A; i++) { c += ldsd[i] / ps; ldsd[i] = c; } // cumsum
+        }
+        __syncthreads();
+        const double last = ldsd[A - 1];
+        uint2 key = make_uint2((uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
+        uint4 r = philox(make_uint4((uint32_t)S->game_idx, (uint32_t)(S->game_idx >> 32), (uint32_t)ply, 0x22222222u), key);
+        const double u = u01(r.x, r.y);
+        int cnt = 0;
+        for (int i = lane; i < A; i += WAVE)
+            cnt += (ldsd[i] / last <= u) ? 1 : 0; // searchsorted(side='right')
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        mv = cnt;
+        if (mv >= A) { // unreachable (cdf[-1]/last == 1 > u); fall back to the most visited move
+            int bv = -1, bidx = 0;
+            for (int i = 0; i < A; i++) { int vc = (int)(NS0[i] & NS_MASK); if (vc > bv) { bv = vc; bidx = i; } }
+            mv = bidx;
+        }
+        __syncthreads();
+    }
+    // ---- row of get_datasets for this root (self_play.py:107-117) ----
+    const int r = S->n_rows;
+    if (r < rcap) {
+        int16_t *rx = B.row_x + ((size_t)slot * rcap + r) * F;
+        for (int i = lane; i < F; i += WAVE) rx[i] = (int16_t)gs_feature(g, rm.st, i);
+        int32_t *rv = B.row_vis + ((size_t)slot * rcap + r) * A;
+        for (int i = lane; i < A; i += WAVE) rv[i] = (int32_t)(NS0[i] & NS_MASK);
+        if (lane == 0) {
+            RowMeta mm;
+            mm.game_idx = (int32_t)S->game_idx;
+            mm.move_idx = (int16_t)ply;
+            mm.move = (int16_t)rm.move;
+            mm.played = (int16_t)mv;
+            mm.max_deepness = (int16_t)(S->max_deepness - S->deepness_correction);
+            mm.tree_size = S->tree_size;
+            mm.terminal_count = S->terminal_count;
+            mm.q_value = S->root_W / (float)(1 + S->root_N); // TreeRoot.get_tree_stats, mcts.py:33-36
+            mm.player = (int8_t)rm.st.to_play;
+            mm.z = 0;
+            mm.pad = 0;
+            B.row_meta[(size_t)slot * rcap + r] = mm;
+        }
+        S->n_rows = r + 1;
+    }
+    __syncthreads();
+    // ---- init_mcts_tree ----
+    int err = reroot(g, B, slot, S, pool, mv, cfg.reuse_tree, marks, lane);
+    if (err) {
+        if (lane == 0) { S->error = err; S->phase = PH_ERROR; }
+        return;
+    }
+    S->move_idx = ply + 1;
+    if (lane == 0) atomicAdd((unsigned long long *)B.moves_played, 1ull);
+    NodeMeta nm = load_meta(pool, g, 0);
+    if (nm.flags & NF_TERMINAL) {
+        if (try_emit(g, B, slot, S, pool, lane))
+            next_game_or_idle(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
+        else
+            S->phase = PH_EMIT;
+        return;
+    }
+    start_move_search(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
+}
+
+// ------------------------------------------------------------------------------------
+// readback helpers + batched rules kernels (one thread per state)
+// ------------------------------------------------------------------------------------
+__global__ void k_get_roots(Geo g, TreeBufs B, int n_slots, double *priors, float *tv, int32_t *nv, int32_t *changed,
+                            int32_t *stats, float *q, float *root_tv, int32_t *root_nv, uint64_t *edges,
+                            int16_t *b2c2, int8_t *to_play, int8_t *just_played, int8_t *result, int8_t *expanded)
+{
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot >= n_slots) return;
+    Slot *S = B.slots + slot;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    NodeMeta rm = load_meta(pool, g, 0);
+    const uint32_t *nd = node_ptr(pool, g, 0);
+    const int A = g.A;
+    for (int i = lane; i < A; i += WAVE) {
+        uint32_t ns = nd[META_DW + 2 * g.AS + i];
+        int c = (int)nd[META_DW + 3 * g.AS + i];
+        if (priors) {
+            double p;
+            if (S->root_prepped) p = B.root_prior[(size_t)slot * g.AS + i];
+            else p = (rm.flags & NF_EXPANDED) && !(rm.flags & NF_TERMINAL)
+                         ? (double)reinterpret_cast<const float *>(nd + META_DW)[i] : 0.0;
+            priors[(size_t)slot * A + i] = p;
+        }
+        if (tv) tv[(size_t)slot * A + i] = reinterpret_cast<const float *>(nd + META_DW + g.AS)[i];
+        if (nv) nv[(size_t)slot * A + i] = (int32_t)(ns & NS_MASK);
+        if (changed) {
+            // child_player_changed: 1 until the child is expanded, then +/-1 (mcts.py:61-62,119)
+            int ch = 1;
+            if (c >= 0) {
+                NodeMeta cm = load_meta(pool, g, c);
+                if (cm.flags & NF_EXPANDED) ch = (ns & NS_SAME) ? 1 : -1;
+            }
+            changed[(size_t)slot * A + i] = ch;
+        }
+    }
+    if (lane == 0) {
+        if (stats) {
+            stats[slot * 3 + 0] = S->max_deepness - S->deepness_correction;
+            stats[slot * 3 + 1] = S->tree_size;
+            stats[slot * 3 + 2] = S->terminal_count;
+        }
+        if (q) q[slot] = S->root_W / (float)(1 + S->root_N);
+        if (root_tv) root_tv[slot] = S->root_W;
+        if (root_nv) root_nv[slot] = S->root_N;
+        if (edges) {
+            edges[slot * 4 + 0] = rm.st.e0; edges[slot * 4 + 1] = rm.st.e1;
+            edges[slot * 4 + 2] = rm.st.e2; edges[slot * 4 + 3] = rm.st.e3;
+        }
+        if (b2c2) { b2c2[slot * 2] = (int16_t)rm.st.b2c0; b2c2[slot * 2 + 1] = (int16_t)rm.st.b2c1; }
+        if (to_play) to_play[slot] = (int8_t)rm.st.to_play;
+        if (just_played) just_played[slot] = (int8_t)rm.st.just_played;
+        if (result) result[slot] = (int8_t)gs_result(rm.st);
+        if (expanded) expanded[slot] = (rm.flags & NF_EXPANDED) ? 1 : 0;
+    }
+}
+
+__global__ void k_get_leaves(Geo g, TreeBufs B, int n_slots, int16_t *leaf_x, uint8_t *need_eval, int32_t *n_active)
+{
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    Slot *S = B.slots + slot;
+    const bool active = S->phase == PH_EXPAND_ROOT || S->phase == PH_SIMS;
+    const bool need = active && !S->leaf_terminal;
+    const int F = 3 * g.HW;
+    const float *f = B.feat + (size_t)slot * F;
+    for (int i = lane; i < F; i += WAVE)
+        leaf_x[(size_t)slot * F + i] = need ? (int16_t)f[i] : (int16_t)0;
+    if (lane == 0) {
+        need_eval[slot] = need ? 1 : 0;
+        if (active) atomicAdd(n_active, 1);
+    }
+}
+
+__global__ void k_count_active(TreeBufs B, int n_slots, int32_t *out /*[3]: searching, ready, error*/)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    int ph = B.slots[i].phase;
+    if (ph == PH_EXPAND_ROOT || ph == PH_SIMS) atomicAdd(out + 0, 1);
+    else if (ph == PH_READY || ph == PH_EMIT) atomicAdd(out + 1, 1);
+    else if (ph == PH_ERROR) atomicAdd(out + 2, 1);
+}
+
+__global__ void k_rules(Geo g, int op, int n, uint64_t *edges, int16_t *b2c2, int8_t *to_play, int8_t *just_played,
+                        const int32_t *moves, int8_t *n_closed, int8_t *closed_lc, uint8_t *valid, int8_t *result,
+                        int16_t *x)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    GState s;
+    gs_init(g, s);
+    if (op != 0) {
+        if (edges) { s.e0 = edges[4 * i]; s.e1 = edges[4 * i + 1]; s.e2 = edges[4 * i + 2]; s.e3 = edges[4 * i + 3]; }
+        if (b2c2) { s.b2c0 = b2c2[2 * i]; s.b2c1 = b2c2[2 * i + 1]; }
+        if (to_play) s.to_play = to_play[i];
+        if (just_played) s.just_played = just_played[i];
+    }
+    bool wb = false;
+    switch (op) {
+    case 0: wb = true; break;                                  // __init__
+    case 1:                                                    // get_valid_moves
+        for (int k = 0; k < g.A; k++) valid[(size_t)i * g.A + k] = gs_valid(g, s, k) ? 1 : 0;
+        break;
+    case 2: {                                                  // play_
+        int cl[4] = {-1, -1, -1, -1};
+        int r = gs_play(g, s, moves[i], cl);
+        n_closed[i] = (int8_t)r;
+        if (closed_lc) for (int k = 0; k < 4; k++) closed_lc[4 * i + k] = (int8_t)((r > 0 && k < 2 * r) ? cl[k] : -1);
+        wb = r >= 0;
+        break;
+    }
+    case 3: result[i] = (int8_t)gs_result(s); break;           // get_result
+    case 4:                                                    // get_features
+        for (int k = 0; k < 3 * g.HW; k++) x[(size_t)i * 3 * g.HW + k] = (int16_t)gs_feature(g, s, k);
+        break;
+    }
+    if (wb) {
+        edges[4 * i] = s.e0; edges[4 * i + 1] = s.e1; edges[4 * i + 2] = s.e2; edges[4 * i + 3] = s.e3;
+        b2c2[2 * i] = (int16_t)s.b2c0; b2c2[2 * i + 1] = (int16_t)s.b2c1;
+        to_play[i] = (int8_t)s.to_play;
+        just_played[i] = (int8_t)s.just_played;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------
+static size_t marks_bytes(const Geo &g) { return (size_t)((g.cap + 63) / 64 + 1) * sizeof(uint64_t); }
+
+void tree_launch_search_begin(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots,
+                              const int32_t *num_reads_dev)
+{
+    hipLaunchKernelGGL(k_search_begin, dim3(n_slots), dim3(WAVE), 0, s, g, c, B, num_reads_dev);
+}
+void tree_launch_select(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
+{
+    hipLaunchKernelGGL(k_select, dim3(n_slots), dim3(WAVE), 0, s, g, c, B);
+}
+void tree_launch_expand_backup(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
+{
+    hipLaunchKernelGGL(k_expand_backup, dim3(n_slots), dim3(WAVE), 0, s, g, c, B);
+}
+void tree_launch_set_positions(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots,
+                               const int16_t *moves_dev, const int32_t *offsets_dev)
+{
+    hipLaunchKernelGGL(k_set_positions, dim3(n_slots), dim3(WAVE), 0, s, g, c, B, moves_dev, offsets_dev);
+}
+void tree_launch_advance_manual(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots,
+                                const int32_t *moves_dev, int reuse)
+{
+    hipLaunchKernelGGL(k_advance_manual, dim3(n_slots), dim3(WAVE), marks_bytes(g), s, g, c, B, moves_dev, reuse);
+}
+void tree_launch_selfplay_start(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
+{
+    hipLaunchKernelGGL(k_selfplay_start, dim3(n_slots), dim3(WAVE), 0, s, g, c, B);
+}
+void tree_launch_advance_auto(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
+{
+    hipLaunchKernelGGL(k_advance_auto, dim3(n_slots), dim3(WAVE), marks_bytes(g), s, g, c, B);
+}
+void tree_launch_get_roots(hipStream_t s, const Geo &g, const TreeBufs &B, int n_slots, double *priors, float *tv,
+                           int32_t *nv, int32_t *changed, int32_t *stats, float *q, float *root_tv, int32_t *root_nv,
+                           uint64_t *edges, int16_t *b2c2, int8_t *to_play, int8_t *just_played, int8_t *result,
+                           int8_t *expanded)
+{
+    hipLaunchKernelGGL(k_get_roots, dim3(n_slots), dim3(WAVE), 0, s, g, B, n_slots, priors, tv, nv, changed, stats, q,
+                       root_tv, root_nv, edges, b2c2, to_play, just_played, result, expanded);
+}
+void tree_launch_get_leaves(hipStream_t s, const Geo &g, const TreeBufs &B, int n_slots, int16_t *leaf_x,
+                            uint8_t *need_eval, int32_t *n_active)
+{
+    hipLaunchKernelGGL(k_get_leaves, dim3(n_slots), dim3(WAVE), 0, s, g, B, n_slots, leaf_x, need_eval, n_active);
+}
+void tree_launch_count_active(hipStream_t s, const TreeBufs &B, int n_slots, int32_t *out3)
+{
+    hipLaunchKernelGGL(k_count_active, dim3((n_slots + 255) / 256), dim3(256), 0, s, B, n_slots, out3);
+}
+void tree_launch_rules(hipStream_t s, const Geo &g, int op, int n, uint64_t *edges, int16_t *b2c2, int8_t *to_play,
+                       int8_t *just_played, const int32_t *moves, int8_t *n_closed, int8_t *closed_lc, uint8_t *valid,
+                       int8_t *result, int16_t *x)
+{
+    hipLaunchKernelGGL(k_rules, dim3((n + 127) / 128), dim3(128), 0, s, g, op, n, edges, b2c2, to_play, just_played,
+                       moves, n_closed, closed_lc, valid, result, x);
+}

@@ -1,0 +1,185 @@
+/*
+ * dbaz.h -- C ABI of the MI355X-native self-play rollout engine (libdbaz_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of damlobster/DotsBoxesAZ:
+ * rules + sequential PUCT search + batched policy/value evaluation + the
+ * self-play driver.  The reference has no FFI layer of its own (it is pure
+ * Python); each entry point below names the reference interface it replaces
+ * (file:line relative to the reference repo).  The ctypes binding a maintainer
+ * would add on the reference side is shown in INTEGRATION.md and shipped in
+ * dotsboxesaz_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a DBAZ_E* code otherwise;
+ *     dbaz_last_error() returns the message (maps to ValueError for
+ *     DBAZ_EILLEGAL, RuntimeError otherwise);
+ *   - all pointers are HOST pointers unless the name ends in _dev; the caller
+ *     owns every buffer; no torch types, no C++ types;
+ *   - a handle is single-threaded; one handle per GPU / rank; no process-global
+ *     state (board size is per handle, unlike BoxesState.init_static_fields);
+ *   - there is NO CPU fallback: without a HIP device dbaz_create fails.
+ *
+ * Board geometry: rows x cols boxes, H = rows+1, W = cols+1, A = 2*H*W action
+ * slots, action = p*H*W + l*W + c (dots_boxes_game.py:62).  A <= 256.
+ */
+#ifndef DBAZ_H
+#define DBAZ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBAZ_OK 0
+#define DBAZ_EINVAL 1   /* bad argument */
+#define DBAZ_EILLEGAL 2 /* illegal move (reference: ValueError, dots_boxes_game.py:63-65) */
+#define DBAZ_EDEVICE 3  /* HIP runtime error / no device */
+#define DBAZ_EPOOL 4    /* per-game node pool exhausted: raise nodes_per_slot */
+#define DBAZ_ESTATE 5   /* call sequence error */
+
+#define DBAZ_MAX_A 256
+#define DBAZ_RESULT_NONE 2
+
+/* evaluator kinds (what plays the role of async_nn, mcts.py:187) */
+#define DBAZ_EVAL_FORMULA_HASH 0    /* integer-hash priors/value (bit-exact test evaluator) */
+#define DBAZ_EVAL_FORMULA_UNIFORM 1 /* uniform priors, v = 0 (tree + rules only) */
+#define DBAZ_EVAL_RESNET 2          /* ResNetZero, HIP MFMA kernels (nn.py:108-122) */
+#define DBAZ_EVAL_SIMPLENN 3        /* SimpleNN, 3x3 boards (dots_boxes_nn.py:61-98) */
+#define DBAZ_EVAL_EXTERNAL 4        /* caller supplies (p, v) per leaf: dbaz_select / dbaz_expand_backup */
+
+typedef struct dbaz_engine dbaz_engine;
+
+/* configuration.py:82-100 values + sizing */
+typedef struct {
+    int32_t rows, cols;
+    int32_t n_slots;        /* concurrent games resident on the GPU */
+    int32_t nodes_per_slot; /* node pool per game; 0 = 6*(mcts_num_read+2) */
+    int32_t mcts_num_read;  /* self_play.mcts.mcts_num_read */
+    double cpuct, cpuct_base; /* self_play.mcts.mcts_cpuct */
+    double noise_alpha, noise_coeff; /* self_play.noise */
+    int32_t reuse_tree;     /* self_play.reuse_mcts_tree */
+    int32_t n_temp;         /* self_play.mcts.temperature {move_idx: T} */
+    int32_t temp_idx[8];
+    double temp_val[8];
+    int32_t evaluator;      /* DBAZ_EVAL_* */
+    int32_t device;         /* HIP device ordinal */
+    uint64_t seed;          /* Philox key for move sampling / Dirichlet noise */
+    int32_t max_out_rows;   /* capacity of the finished-sample buffer; 0 = n_slots*(E+1) */
+    int32_t nn_precision;   /* 0 = exact f32 MFMA; 1 = f16x3 split MFMA (f32-grade) */
+} dbaz_config;
+
+typedef struct {
+    int64_t steps;          /* simulation steps launched */
+    int64_t expansions;     /* completed _search calls (node expansions) */
+    int64_t nn_evals;       /* leaves sent to the evaluator */
+    int64_t terminal_leaves;
+    int64_t sum_path;       /* sum over expansions of the search-path length (nodes) */
+    int64_t games_finished;
+    int64_t rows_ready;     /* sample rows waiting in the output buffer */
+    int64_t moves_played;
+    int64_t pool_high_water;/* max nodes in use in any slot */
+    int32_t active_slots;   /* slots still playing */
+    int32_t error_slots;    /* slots stopped by an error (pool exhausted) */
+    /* HIP-event timing of the last timed region (dbaz_timing_begin/_end) */
+    double ms_total, ms_tree, ms_nn;
+    int64_t nn_launches;    /* conv-tower launches inside the timed region */
+    double ms_nn_tower;     /* summed duration of the dominant conv kernel */
+} dbaz_counters;
+
+const char *dbaz_last_error(const dbaz_engine *e); /* e may be NULL: error of the last dbaz_create */
+int dbaz_version(void);
+
+int dbaz_create(const dbaz_config *cfg, dbaz_engine **out);
+void dbaz_destroy(dbaz_engine *e);
+int dbaz_sync(dbaz_engine *e);
+
+/* ---- G1-G6: batched rules on SoA states (dots_boxes_game.py:30-109) --------------
+ * state i = { edges[4*i..4*i+3] : bitmask of played edges (= hash[0], :106-109),
+ *             b2c2[2*i..2*i+1]  : 2*boxes_to_close (integers; :39,:86),
+ *             to_play[i], just_played[i] (-1 = None) } */
+int dbaz_rules_init(dbaz_engine *e, int32_t n, uint64_t *edges, int16_t *b2c2, int8_t *to_play,
+                    int8_t *just_played);                                   /* __init__ :30-39 */
+int dbaz_rules_valid_moves(dbaz_engine *e, int32_t n, const uint64_t *edges,
+                           uint8_t *valid /*[n*A]*/);                       /* get_valid_moves :44-49 */
+int dbaz_rules_play(dbaz_engine *e, int32_t n, uint64_t *edges, int16_t *b2c2, int8_t *to_play,
+                    int8_t *just_played, const int32_t *moves,
+                    int8_t *n_closed /*[n]; -1 = illegal, state untouched*/,
+                    int8_t *closed_lc /*[n*4] (l,c) pairs, -1 padded; may be NULL*/); /* play_ :61-89 */
+int dbaz_rules_result(dbaz_engine *e, int32_t n, const int16_t *b2c2, const int8_t *to_play,
+                      int8_t *result /* 1,0,-1 or DBAZ_RESULT_NONE */);    /* get_result :51-59 */
+int dbaz_rules_features(dbaz_engine *e, int32_t n, const uint64_t *edges, const int16_t *b2c2,
+                        const int8_t *to_play, int16_t *x /*[n*3*H*W]*/);  /* get_features :96-100 */
+
+/* ---- N1-N3: policy/value network (nn.py:108-129,155-160; dots_boxes_nn.py:61-105) ----
+ * Weights arrive as state_dict entries under the reference's key names
+ * ("resnet.resblocks.3.conv1.weight", ...), any order; dbaz_nn_commit folds the
+ * eval-mode BatchNorms and uploads. */
+int dbaz_nn_configure(dbaz_engine *e, int32_t kind /*DBAZ_EVAL_RESNET|SIMPLENN*/, int32_t channels,
+                      int32_t blocks, int32_t head_channels, int32_t value_fc);
+int dbaz_nn_set_tensor(dbaz_engine *e, const char *key, const float *data, int64_t numel);
+int dbaz_nn_commit(dbaz_engine *e);
+/* NeuralNetWrapper.predict_sync: X float32 [n,3,H,W] -> softmax p [n,A], tanh v [n] */
+int dbaz_nn_predict(dbaz_engine *e, int32_t n, const float *X, float *p, float *v);
+
+/* ---- M1-M9: batched sequential search, one tree per slot (mcts.py) ----------------- */
+/* per-call arguments of UCT_search: cpuct=(c, base), dirichlet=(alpha, coeff) (mcts.py:183,205,211) */
+int dbaz_set_search_params(dbaz_engine *e, double cpuct, double cpuct_base, double noise_alpha, double noise_coeff);
+/* create_root_uct_node for every slot: slot i starts from the position reached by
+ * moves[offsets[i]..offsets[i+1]) (NULL, NULL = empty boards).  mcts.py:156-160 */
+int dbaz_set_positions(dbaz_engine *e, const int16_t *moves, const int32_t *offsets);
+/* UCT_search on every slot with max_pending_evals=1 semantics (mcts.py:183-244).
+ *   num_reads[n_slots]  NULL = the driver rule min(4*n_valid!, mcts_num_read) (self_play.py:64-65)
+ *   noise[n_slots*A]    Dirichlet sample per slot over ALL A slots (used if noise_alpha>0);
+ *                       NULL = drawn on the device (Philox)
+ * Blocks until every slot finished its reads.  Not for DBAZ_EVAL_EXTERNAL. */
+int dbaz_search(dbaz_engine *e, const int32_t *num_reads, const double *noise);
+/* external-evaluator form of the same call: begin, then loop
+ *   dbaz_select -> (evaluate leaves on the host) -> dbaz_expand_backup  until *n_active == 0 */
+int dbaz_search_begin(dbaz_engine *e, const int32_t *num_reads, const double *noise);
+int dbaz_select(dbaz_engine *e, int32_t *n_active,
+                int16_t *leaf_x /*[n_slots*3HW] get_features of each leaf*/,
+                uint8_t *need_eval /*[n_slots] 1 = non-terminal leaf of an active slot*/);
+int dbaz_expand_backup(dbaz_engine *e, const float *p /*[n_slots*A]*/, const float *v /*[n_slots]*/);
+/* root arrays after a search (what UCT_search returns / tests inspect); any pointer may be NULL */
+int dbaz_get_roots(dbaz_engine *e, double *priors /*[n*A]*/, float *total_value /*[n*A]*/,
+                   int32_t *visits /*[n*A]*/, int32_t *changed /*[n*A]*/,
+                   int32_t *stats /*[n*3]: max_deepness, tree_size, terminal_count*/,
+                   float *q_value /*[n]*/, float *root_tv /*[n]*/, int32_t *root_nv /*[n]*/);
+/* root game states (edges/b2c2/to_play/just_played/result/expanded) */
+int dbaz_get_root_states(dbaz_engine *e, uint64_t *edges, int16_t *b2c2, int8_t *to_play,
+                         int8_t *just_played, int8_t *result, int8_t *expanded);
+/* init_mcts_tree on every slot (mcts.py:163-180); moves[i] < 0 leaves slot i alone */
+int dbaz_advance(dbaz_engine *e, const int32_t *moves, int32_t reuse_tree);
+
+/* ---- D1-D3: self-play driver (self_play.py:19-156) ---------------------------------- */
+/* Start playing games first_game_idx .. first_game_idx+n_games-1; every slot takes the next
+ * unplayed index when its game ends (generate_games' chunking, self_play.py:291-306). */
+int dbaz_selfplay_start(dbaz_engine *e, int64_t n_games, int64_t first_game_idx);
+/* teacher forcing for parity tests: moves / Dirichlet vectors for game `game_idx`
+ * (noise may be NULL).  Must be called before dbaz_selfplay_start. */
+int dbaz_selfplay_script(dbaz_engine *e, int64_t game_idx, const int16_t *moves, int32_t n_moves,
+                         const double *noise /*[n_moves*A]*/);
+/* synthetic mid-game population for benchmarking: slot i is advanced by plies[i]
+ * uniformly random legal moves before its first search. */
+int dbaz_selfplay_fastforward(dbaz_engine *e, const int32_t *plies);
+int dbaz_step(dbaz_engine *e, int32_t k);             /* k simulation steps, asynchronous */
+int dbaz_run(dbaz_engine *e, int64_t max_steps);       /* until all games are finished */
+int dbaz_get_counters(dbaz_engine *e, dbaz_counters *out);
+int dbaz_timing_begin(dbaz_engine *e);
+int dbaz_timing_end(dbaz_engine *e);
+/* SelfPlay.get_datasets rows of finished games (self_play.py:95-156), sorted by
+ * (game_idx, move_idx).  Drains the output buffer. */
+int dbaz_fetch_samples(dbaz_engine *e, int32_t max_rows, int32_t *n_rows,
+                       int32_t *game_idx, int16_t *move_idx, int16_t *move, int8_t *player,
+                       int16_t *x /*[rows*3HW]*/, int32_t *visits /*[rows*A]*/, double *pi /*[rows*A]*/,
+                       int8_t *z, int16_t *max_deepness, int32_t *tree_size, int32_t *terminal_count,
+                       float *q_value, int16_t *played);
+/* device-resident replay rows for the RCCL all-gather (multi-GPU iteration end):
+ * fixed-stride packed rows, see DESIGN.md "replay row".  Returns a DEVICE pointer. */
+int dbaz_replay_rows_dev(dbaz_engine *e, void **rows_dev, int32_t *n_rows, int32_t *row_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,54 @@
+"""The C-ABI library loads and exports every symbol include/dbaz.h declares
+(no compute calls: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+from dotsboxesaz_amd import _lib
+
+
+def header_symbols():
+    src = open(os.path.join(REPO, "include", "dbaz.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dbaz_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        from dotsboxesaz_amd import build
+        build.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(L, name), name
+    assert _lib.load().dbaz_version() == 1
+
+
+def test_struct_sizes_match_header():
+    # dbaz_config / dbaz_counters layouts as the C compiler sees them
+    assert ctypes.sizeof(_lib.Config) == 184
+    assert ctypes.sizeof(_lib.Counters) == 120
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dotsboxesaz_amd.engine import Engine
+    with pytest.raises(_lib.DbazError) as ei:
+        Engine(3, 3, 4)
+    assert "no CPU fallback" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_bad_config_rejected_before_touching_the_device():
+    from dotsboxesaz_amd.engine import Engine
+    with pytest.raises(_lib.DbazError):
+        Engine(12, 12, 4)  # A = 338 > 256
+    with pytest.raises(_lib.DbazError):
+        Engine(3, 3, 0)

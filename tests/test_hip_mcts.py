@@ -1,0 +1,171 @@
+"""HIP tree kernels (select / expand / backup / re-root) through the C ABI vs the
+reference's golden vectors and the oracle -- rows M1-M9.  Bit-exact: visit counts,
+float32 W bit patterns, float64 root priors, TreeStats."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+_G = load_golden("mcts.npz")
+CASES = [str(c) for c in _G["cases"]]
+
+
+class HipTree:
+    """Two identical slots (slot independence) driven like mcts.UCT_search / init_mcts_tree."""
+
+    def __init__(self, rows, cols, start, kind, cap=0):
+        from dotsboxesaz_amd.engine import Engine
+        self.e = Engine(rows, cols, 2, mcts_num_read=800, evaluator="uniform" if kind == 1 else "formula",
+                        nodes_per_slot=cap)
+        self.e.set_positions([list(start), list(start)])
+
+    def search(self, n, cpuct, dirichlet, noise):
+        self.e.set_search_params(cpuct, dirichlet)
+        nz = None if noise is None else np.stack([noise, noise])
+        self.e.search(n, nz)
+        return self.e.roots()
+
+    def advance(self, move, reuse):
+        self.e.advance(move, reuse)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_case(name):
+    g = _G
+    rows, cols, kind, c0, c1 = g[name + "_cfg"]
+    t = HipTree(int(rows), int(cols), g[name + "_start"], int(kind))
+    for si, (op, a, b, c) in enumerate(g[name + "_script"]):
+        key = "%s_s%d_" % (name, si)
+        if op == 0:
+            noise = g[key + "noise"] if b > 0 else None
+            r = t.search(int(a), (c0, c1), (b, c), noise)
+            for s in (0, 1):
+                assert np.array_equal(r["visits"][s], g[key + "visits"]), key
+                assert np.array_equal(r["total_value"][s].view(np.uint32), g[key + "total_value"].view(np.uint32)), key
+                assert np.array_equal(r["priors"][s].view(np.uint64), g[key + "priors"].view(np.uint64)), key
+                assert np.array_equal(r["changed"][s], g[key + "changed"]), key
+                assert list(r["stats"][s]) == list(g[key + "stats_i"]), key
+                assert r["q"][s].view(np.uint32) == g[key + "q"].view(np.uint32), key
+                assert r["root_nv"][s] == g[key + "root_nv"]
+                assert r["root_tv"][s].view(np.uint32) == g[key + "root_tv"].view(np.uint32)
+        else:
+            t.advance(int(a), bool(b))
+    t.e.close()
+
+
+@pytest.mark.parametrize("rows,cols,n_slots,sims,kind", [(3, 3, 512, 120, 0), (6, 6, 384, 200, 0), (6, 6, 64, 300, 1),
+                                                         (9, 9, 96, 150, 0), (2, 4, 128, 90, 0)])
+def test_many_slots_vs_oracle(rows, cols, n_slots, sims, kind):
+    """Every slot searches a different position; three searches with tree reuse, noise on the
+    second one; root arrays compared with the C oracle slot by slot."""
+    from dotsboxesaz_amd.engine import Engine
+    d = O.dims(rows, cols)
+    rng = np.random.RandomState(n_slots + sims)
+    starts = []
+    for s in range(n_slots):
+        st = O.new_state(d)
+        mv = []
+        for _ in range(rng.randint(0, d.A // 3)):
+            legal = np.nonzero(O.valid_moves(d, st))[0]
+            m = int(legal[rng.randint(len(legal))])
+            tmp = st.copy()
+            O.play_(d, tmp, m)
+            if O.get_result(tmp) is not None:
+                break
+            st = tmp
+            mv.append(m)
+        starts.append(mv)
+    e = Engine(rows, cols, n_slots, mcts_num_read=sims, evaluator="uniform" if kind else "formula")
+    e.set_positions(starts)
+    trees = [O.Tree(d, O.state_from_moves(d, mv)) for mv in starts]
+    ev = O.Evaluator(kind)
+    reads = rng.randint(1, sims + 1, size=n_slots).astype(np.int32)
+    for rnd, (alpha, coeff) in enumerate([(0.0, 0.0), (0.8, 0.25), (0.0, 0.0)]):
+        noise = rng.dirichlet(np.full(d.A, 0.8), size=n_slots) if alpha > 0 else None
+        e.set_search_params((1.25, 19652), (alpha, coeff))
+        e.search(reads, noise)
+        r = e.roots()
+        moves = np.zeros(n_slots, np.int32)
+        for s in range(n_slots):
+            vis = trees[s].search(int(reads[s]), ev, dirichlet=(alpha, coeff), noise=None if noise is None else noise[s])
+            pri, tv, nv, pc = trees[s].root_arrays()
+            assert np.array_equal(r["visits"][s], vis), (rnd, s)
+            assert np.array_equal(r["total_value"][s].view(np.uint32), tv.view(np.uint32)), (rnd, s)
+            assert np.array_equal(r["priors"][s].view(np.uint64), pri.view(np.uint64)), (rnd, s)
+            md, ts, tc, q = trees[s].stats()
+            assert list(r["stats"][s]) == [md, ts, tc]
+            assert r["q"][s].view(np.uint32) == np.float32(q).view(np.uint32)
+            # half the slots follow the most visited move, the rest a random legal one
+            if s % 2 == 0:
+                moves[s] = int(np.argmax(vis))
+            else:
+                legal = np.nonzero(O.valid_moves(d, trees[s].state))[0]
+                moves[s] = int(legal[rng.randint(len(legal))])
+        for s in range(n_slots):
+            tmp = trees[s].state
+            O.play_(d, tmp, int(moves[s]))
+            if O.get_result(tmp) is not None:
+                moves[s] = -1  # do not walk into a terminal root (nothing to search there)
+            else:
+                trees[s].advance(int(moves[s]), True)
+        e.advance(moves, True)
+    e.close()
+
+
+def test_illegal_advance_raises_value_error():
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(3, 3, 2, mcts_num_read=10)
+    e.set_positions(None)
+    e.search(5)
+    e.advance([0, 1])
+    with pytest.raises(ValueError):
+        e.advance([0, 2])
+    e.close()
+
+
+def test_pool_exhaustion_is_reported():
+    from dotsboxesaz_amd import _lib
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(3, 3, 2, mcts_num_read=200, nodes_per_slot=16)
+    e.set_positions(None)
+    with pytest.raises(_lib.DbazError) as ei:
+        e.search(200)
+    assert ei.value.code == _lib.EPOOL
+    e.close()
+
+
+def test_external_evaluator_matches_internal_formula():
+    """dbaz_select / dbaz_expand_backup with host-computed (p, v) == device formula evaluator."""
+    from dotsboxesaz_amd.engine import Engine
+    d = O.dims(3, 3)
+    a = Engine(3, 3, 8, mcts_num_read=60, evaluator="formula")
+    b = Engine(3, 3, 8, mcts_num_read=60, evaluator="external")
+    a.set_positions(None)
+    b.set_positions(None)
+
+    def evaluate(x):
+        # rebuild the states from the features (planes 0,1 = edges; plane 2 = 2*boxes_to_close[to_play])
+        P, V = [], []
+        for f in x:
+            s = O.new_state(d)
+            bits = np.nonzero(f[:2].ravel())[0]
+            for m in bits:
+                s.board[int(m)] = 255
+                s.hash_bits[int(m) >> 6] |= 1 << (int(m) & 63)
+            s.to_play = 0
+            s.b2c2[0] = int(f[2, 0, 0])
+            p, v = O.eval_formula(d, s)
+            P.append(p)
+            V.append(v)
+        return np.stack(P), np.array(V)
+
+    a.search(60)
+    b.search_external(evaluate, 60)
+    ra, rb = a.roots(), b.roots()
+    for k in ("visits", "total_value", "priors"):
+        assert np.array_equal(ra[k], rb[k]), k
+    a.close()
+    b.close()
