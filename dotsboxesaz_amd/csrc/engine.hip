@@ -197,7 +197,8 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     memset(&B, 0, sizeof(B));
     const size_t ns = e->n_slots;
     const int F = 3 * g.HW, rcap = g.E + 1;
-    B.max_out = cfg->max_out_rows > 0 ? cfg->max_out_rows : (int32_t)std::min<size_t>(ns * rcap, (size_t)1 << 26);
+    B.max_out = cfg->max_out_rows > 0 ? cfg->max_out_rows : (int32_t)std::min<size_t>(std::max<size_t>(4096, 2 * ns * rcap), (size_t)1 << 26);
+    if (B.max_out < rcap) { set_error(nullptr, DBAZ_EINVAL, "max_out_rows must hold at least one game (%d rows)", rcap); dbaz_destroy(e); return DBAZ_EINVAL; }
     CREATE_CHECK(dmalloc(e, &B.nodes, ns * g.cap * g.node_dw, false));
     CREATE_CHECK(dmalloc(e, &B.slots, ns));
     CREATE_CHECK(dmalloc(e, &B.path, ns * g.dmax));
@@ -779,7 +780,7 @@ static int slot_summary(dbaz_engine *e, dbaz_counters *c)
     std::vector<Slot> hs(e->n_slots);
     HIP_CHECK_RET(e, hipMemcpy(hs.data(), e->B.slots, sizeof(Slot) * e->n_slots, hipMemcpyDeviceToHost));
     c->expansions = c->nn_evals = c->terminal_leaves = c->sum_path = 0;
-    c->active_slots = c->error_slots = 0;
+    c->active_slots = c->error_slots = c->blocked_slots = 0;
     c->pool_high_water = 0;
     for (const Slot &s : hs) {
         c->expansions += s.n_search;
@@ -788,6 +789,7 @@ static int slot_summary(dbaz_engine *e, dbaz_counters *c)
         c->sum_path += s.sum_path;
         if (s.phase == PH_ERROR) c->error_slots++;
         else if (s.game_idx >= 0 && s.phase != PH_IDLE) c->active_slots++;
+        if (s.phase == PH_EMIT) c->blocked_slots++;
         c->pool_high_water = std::max<int64_t>(c->pool_high_water, s.pool_high);
     }
     return DBAZ_OK;
@@ -821,13 +823,21 @@ extern "C" int dbaz_run(dbaz_engine *e, int64_t max_steps)
 {
     if (!e) return DBAZ_EINVAL;
     if (!e->selfplay) return set_error(e, DBAZ_ESTATE, "dbaz_selfplay_start not called");
-    int64_t done = 0;
+    int64_t done = 0, last_exp = -1, last_moves = -1;
+    int stalls = 0;
     for (;;) {
         dbaz_counters c;
         int r = dbaz_get_counters(e, &c);
         if (r) return r;
         if (c.error_slots > 0) return check_slot_errors(e);
         if (c.active_slots == 0) return DBAZ_OK;
+        // output buffer full: the caller must fetch.  Only after stepping in THIS call, so that a
+        // call made right after a drain lets the blocked slots emit.
+        if (c.blocked_slots == c.active_slots && done > 0) return DBAZ_OK;
+        if (c.expansions == last_exp && c.moves_played == last_moves) {
+            if (++stalls >= 4) return set_error(e, DBAZ_ESTATE, "self-play made no progress for %d polls", stalls);
+        } else stalls = 0;
+        last_exp = c.expansions; last_moves = c.moves_played;
         if (max_steps > 0 && done >= max_steps) return DBAZ_OK;
         int chunk = 64;
         if (max_steps > 0) chunk = (int)std::min<int64_t>(chunk, max_steps - done);

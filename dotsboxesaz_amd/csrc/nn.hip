@@ -41,7 +41,7 @@ struct ConvLayer {
 struct NNState {
     Geo g;
     int max_batch = 0, precision = 0;
-    int kind = 0, C = 0, blocks = 0, hc = 0, vf = 0;
+    int kind = 0, C = 0 /* padded to 16/32/64/128 */, Craw = 0 /* state_dict channels */, blocks = 0, hc = 0, vf = 0;
     bool ready = false;
     std::map<std::string, std::vector<float>> sd;
     // device
@@ -341,15 +341,14 @@ bool nn_ready(const NNState *nn) { return nn && nn->ready; }
 int nn_configure(NNState *nn, int kind, int channels, int blocks, int head_channels, int value_fc, std::string &err)
 {
     if (kind != DBAZ_EVAL_RESNET) { err = "only DBAZ_EVAL_RESNET is implemented in this build"; return DBAZ_EINVAL; }
-    if (channels != 16 && channels != 32 && channels != 64 && channels != 128) {
-        err = "channels must be one of 16, 32, 64, 128";
-        return DBAZ_EINVAL;
-    }
+    if (channels < 1 || channels > 128) { err = "channels must be in 1..128"; return DBAZ_EINVAL; }
     if (blocks < 0 || head_channels < 1 || value_fc < 1 || value_fc > 64) { err = "bad network shape"; return DBAZ_EINVAL; }
     if (nn->g.A > 256 - value_fc) { err = "A + value_fc must be <= 256"; return DBAZ_EINVAL; }
     nn_free_device(nn);
     nn->sd.clear();
-    nn->kind = kind; nn->C = channels; nn->blocks = blocks; nn->hc = head_channels; nn->vf = value_fc;
+    // the MFMA tile wants 16 | C: narrower nets run zero-padded (padded channels stay exactly 0)
+    int cp = channels <= 16 ? 16 : channels <= 32 ? 32 : channels <= 64 ? 64 : 128;
+    nn->kind = kind; nn->C = cp; nn->Craw = channels; nn->blocks = blocks; nn->hc = head_channels; nn->vf = value_fc;
     return DBAZ_OK;
 }
 
@@ -391,22 +390,24 @@ static bool bn_affine(NNState *nn, const std::string &p, int n, std::vector<doub
 // conv3x3 [C][C][3][3] + following BN -> packed fragment order [C/16][9][C/16][64][4]
 static bool pack_conv(NNState *nn, const std::string &conv, const std::string &bn, int C, ConvLayer &L, std::string &err)
 {
-    auto w = sd_get(nn, conv + ".weight", (size_t)C * C * 9, err); if (!w) return false;
-    auto b = sd_get(nn, conv + ".bias", C, err); if (!b) return false;
+    const int Cr = nn->Craw;
+    auto w = sd_get(nn, conv + ".weight", (size_t)Cr * Cr * 9, err); if (!w) return false;
+    auto b = sd_get(nn, conv + ".bias", Cr, err); if (!b) return false;
     std::vector<double> s, t;
-    if (!bn_affine(nn, bn, C, s, t, err)) return false;
+    if (!bn_affine(nn, bn, Cr, s, t, err)) return false;
     const int KC = C / 16;
-    std::vector<float> pk((size_t)C * C * 9), bias(C);
+    std::vector<float> pk((size_t)C * C * 9, 0.0f), bias(C, 0.0f);
     for (int ct = 0; ct < C / 16; ct++)
         for (int tap = 0; tap < 9; tap++)
             for (int kc = 0; kc < KC; kc++)
                 for (int lane = 0; lane < 64; lane++)
                     for (int e = 0; e < 4; e++) {
                         int co = ct * 16 + (lane & 15), ci = kc * 16 + 4 * (lane >> 4) + e;
-                        double v = (double)(*w)[((size_t)co * C + ci) * 9 + tap] * s[co];
+                        if (co >= Cr || ci >= Cr) continue;
+                        double v = (double)(*w)[((size_t)co * Cr + ci) * 9 + tap] * s[co];
                         pk[((((size_t)ct * 9 + tap) * KC + kc) * 64 + lane) * 4 + e] = (float)v;
                     }
-    for (int co = 0; co < C; co++) bias[co] = (float)((double)(*b)[co] * s[co] + t[co]);
+    for (int co = 0; co < Cr; co++) bias[co] = (float)((double)(*b)[co] * s[co] + t[co]);
     L.w = nn_upload(nn, pk);
     L.bias = nn_upload(nn, bias);
     if (!L.w || !L.bias) { err = "hipMalloc failed (conv weights)"; return false; }
@@ -418,7 +419,7 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     (void)s;
     if (nn->kind != DBAZ_EVAL_RESNET) { err = "dbaz_nn_configure not called"; return DBAZ_ESTATE; }
     const Geo &g = nn->g;
-    const int C = nn->C, hc = nn->hc, vf = nn->vf, HW = g.HW, A = g.A, K = hc * HW;
+    const int C = nn->C, Cr = nn->Craw, hc = nn->hc, vf = nn->vf, HW = g.HW, A = g.A, K = hc * HW;
     for (void *p : nn->allocs) (void)hipFree(p);
     nn->allocs.clear();
     nn->tower.clear();
@@ -433,12 +434,12 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     }
     // conv0 + bn0 -> [9][3][C]
     {
-        auto w = sd_get(nn, "resnet.conv0.weight", (size_t)C * 27, err); if (!w) return DBAZ_EINVAL;
-        auto b = sd_get(nn, "resnet.conv0.bias", C, err); if (!b) return DBAZ_EINVAL;
+        auto w = sd_get(nn, "resnet.conv0.weight", (size_t)Cr * 27, err); if (!w) return DBAZ_EINVAL;
+        auto b = sd_get(nn, "resnet.conv0.bias", Cr, err); if (!b) return DBAZ_EINVAL;
         std::vector<double> sc, tc;
-        if (!bn_affine(nn, "resnet.bn0", C, sc, tc, err)) return DBAZ_EINVAL;
-        std::vector<float> pk((size_t)27 * C), bias(C);
-        for (int co = 0; co < C; co++) {
+        if (!bn_affine(nn, "resnet.bn0", Cr, sc, tc, err)) return DBAZ_EINVAL;
+        std::vector<float> pk((size_t)27 * C, 0.0f), bias(C, 0.0f);
+        for (int co = 0; co < Cr; co++) {
             for (int ci = 0; ci < 3; ci++)
                 for (int tap = 0; tap < 9; tap++)
                     pk[(size_t)(tap * 3 + ci) * C + co] = (float)((double)(*w)[((size_t)co * 3 + ci) * 9 + tap] * sc[co]);
@@ -457,16 +458,16 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     }
     // heads: conv1x1 + BN folded, rows [policy hc | value hc]
     {
-        std::vector<float> hw((size_t)2 * hc * C), hb(2 * hc);
+        std::vector<float> hw((size_t)2 * hc * C, 0.0f), hb(2 * hc);
         const char *heads[2] = {"policy_head", "value_head"};
         for (int h = 0; h < 2; h++) {
             std::string p = heads[h];
-            auto w = sd_get(nn, p + ".conv0.weight", (size_t)hc * C, err); if (!w) return DBAZ_EINVAL;
+            auto w = sd_get(nn, p + ".conv0.weight", (size_t)hc * Cr, err); if (!w) return DBAZ_EINVAL;
             auto b = sd_get(nn, p + ".conv0.bias", hc, err); if (!b) return DBAZ_EINVAL;
             std::vector<double> sc, tc;
             if (!bn_affine(nn, p + ".bn0", hc, sc, tc, err)) return DBAZ_EINVAL;
             for (int o = 0; o < hc; o++) {
-                for (int c = 0; c < C; c++) hw[(size_t)(h * hc + o) * C + c] = (float)((double)(*w)[(size_t)o * C + c] * sc[o]);
+                for (int c = 0; c < Cr; c++) hw[(size_t)(h * hc + o) * C + c] = (float)((double)(*w)[(size_t)o * Cr + c] * sc[o]);
                 hb[h * hc + o] = (float)((double)(*b)[o] * sc[o] + tc[o]);
             }
         }
@@ -558,7 +559,7 @@ double nn_flops_per_sample(const NNState *nn)
 {
     // 2*MAC of conv + FC layers: conv0, 2*blocks tower convs, head convs, FCs
     const Geo &g = nn->g;
-    const double HW = g.HW, C = nn->C, hc = nn->hc, K = hc * HW;
+    const double HW = g.HW, C = nn->Craw, hc = nn->hc, K = hc * HW;
     double f = 2.0 * HW * 27 * C + 2.0 * nn->blocks * 2.0 * HW * 9 * C * C;
     f += 2.0 * 2.0 * HW * C * hc + 2.0 * K * g.A + 2.0 * K * nn->vf + 2.0 * nn->vf;
     return f;

@@ -52,6 +52,7 @@ class Engine:
         cfg.device, cfg.seed, cfg.max_out_rows = int(device), int(seed), int(max_out_rows)
         cfg.nn_precision = int(nn_precision)
         self.cfg = cfg
+        self._drained = []
         self.h = C.c_void_p()
         rc = self._L.dbaz_create(C.byref(cfg), C.byref(self.h))
         if rc != _lib.OK:
@@ -236,7 +237,14 @@ class Engine:
         self._ck(self._L.dbaz_step(self.h, int(k)))
 
     def run(self, max_steps=0):
-        self._ck(self._L.dbaz_run(self.h, int(max_steps)))
+        """Play until every game is finished.  Finished rows that do not fit the device
+        output buffer are drained to the host on the way; fetch_samples() returns them all."""
+        while True:
+            self._ck(self._L.dbaz_run(self.h, int(max_steps)))
+            c = self.counters()
+            if max_steps or c["active_slots"] == 0 or c["blocked_slots"] < c["active_slots"]:
+                return
+            self._drained.append(self._fetch_once())
 
     def sync(self):
         self._ck(self._L.dbaz_sync(self.h))
@@ -253,7 +261,15 @@ class Engine:
         return {k: getattr(c, k) for k, _ in _lib.Counters._fields_}
 
     def fetch_samples(self):
-        """Rows of SelfPlay.get_datasets for the games finished so far (drains the buffer)."""
+        """Rows of SelfPlay.get_datasets for the games finished so far (drains the buffer),
+        sorted by (game_idx, move_idx)."""
+        parts = self._drained + [self._fetch_once()]
+        self._drained = []
+        out = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+        order = np.lexsort((out["move_idx"], out["game_idx"]))
+        return {k: v[order] for k, v in out.items()}
+
+    def _fetch_once(self):
         n = C.c_int32()
         self._ck(self._L.dbaz_fetch_samples(self.h, 0, C.byref(n), *([None] * 13)))
         m = n.value

@@ -65,7 +65,7 @@ typedef struct {
     int32_t evaluator;      /* DBAZ_EVAL_* */
     int32_t device;         /* HIP device ordinal */
     uint64_t seed;          /* Philox key for move sampling / Dirichlet noise */
-    int32_t max_out_rows;   /* capacity of the finished-sample buffer; 0 = n_slots*(E+1) */
+    int32_t max_out_rows;   /* capacity of the finished-sample buffer; 0 = max(4096, 2*n_slots*(E+1)) */
     int32_t nn_precision;   /* 0 = exact f32 MFMA; 1 = f16x3 split MFMA (f32-grade) */
 } dbaz_config;
 
@@ -81,6 +81,8 @@ typedef struct {
     int64_t pool_high_water;/* max nodes in use in any slot */
     int32_t active_slots;   /* slots still playing */
     int32_t error_slots;    /* slots stopped by an error (pool exhausted) */
+    int32_t blocked_slots;  /* finished games waiting for room in the output buffer: fetch samples */
+    int32_t reserved;
     /* HIP-event timing of the last timed region (dbaz_timing_begin/_end) */
     double ms_total, ms_tree, ms_nn;
     int64_t nn_launches;    /* conv-tower launches inside the timed region */
@@ -164,7 +166,9 @@ int dbaz_selfplay_script(dbaz_engine *e, int64_t game_idx, const int16_t *moves,
  * uniformly random legal moves before its first search. */
 int dbaz_selfplay_fastforward(dbaz_engine *e, const int32_t *plies);
 int dbaz_step(dbaz_engine *e, int32_t k);             /* k simulation steps, asynchronous */
-int dbaz_run(dbaz_engine *e, int64_t max_steps);       /* until all games are finished */
+/* until all games are finished, max_steps (if > 0) are done, or every remaining slot is
+ * blocked on a full output buffer (counters.blocked_slots == active_slots: fetch and call again) */
+int dbaz_run(dbaz_engine *e, int64_t max_steps);
 int dbaz_get_counters(dbaz_engine *e, dbaz_counters *out);
 int dbaz_timing_begin(dbaz_engine *e);
 int dbaz_timing_end(dbaz_engine *e);

@@ -1,0 +1,99 @@
+"""HIP policy/value network (MFMA conv tower + heads) through the C ABI vs the
+reference's golden outputs and the torch fp32 restatement -- rows N1, N3.
+Tolerance: 1e-4 absolute on policy and value (north-star, fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def engine_for(rows, cols, model, n_slots=64, precision=0):
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(rows, cols, n_slots, mcts_num_read=8, evaluator="resnet", nn_precision=precision)
+    c = model.cfg
+    e.load_state_dict(model.state_dict(), "resnet", c["channels"], c["blocks"], c["head_channels"], c["value_fc"])
+    return e
+
+
+@pytest.mark.parametrize("tag", ["small33", "small66", "small23"])
+def test_golden_committed_weights(golden_nn, tag):
+    g = golden_nn
+    r, c, ch, nb, hc, vf = [int(x) for x in g[tag + "_cfg"]]
+    m = nn_ref.ResNetZeroRef(r, c, ch, nb, 3, hc, vf)
+    m.load_state_dict({k[len(tag) + 3:]: torch.tensor(g[k]) for k in g.files if k.startswith(tag + "_w_")})
+    e = engine_for(r, c, m)
+    p, v = e.predict(g[tag + "_X"])
+    assert p.shape == g[tag + "_p"].shape and v.shape == g[tag + "_v"].shape
+    assert np.abs(p - g[tag + "_p"]).max() < TOL
+    assert np.abs(v - g[tag + "_v"]).max() < TOL
+    e.close()
+
+
+@pytest.mark.parametrize("tag,rows,cols", [("full33", 3, 3), ("full66", 6, 6), ("full99", 9, 9)])
+def test_golden_full_size(golden_nn, tag, rows, cols):
+    """20 blocks x 64 channels, weights regenerated from the fixture's seed."""
+    g = golden_nn
+    torch.manual_seed(0)
+    m = nn_ref.ResNetZeroRef(rows, cols)
+    nn_ref.randomize_bn(m, 3)
+    e = engine_for(rows, cols, m)
+    p, v = e.predict(g[tag + "_X"])
+    cs = nn_ref.state_dict_checksum(m)
+    if abs(cs - float(g[tag + "_checksum"])) <= 1e-6 * cs:
+        assert np.abs(p - g[tag + "_p"]).max() < TOL
+        assert np.abs(v - g[tag + "_v"]).max() < TOL
+    # always: against the torch fp32 restatement with the very same weights
+    pr, vr = nn_ref.predict_sync(m, g[tag + "_X"])
+    assert np.abs(p - pr).max() < TOL and np.abs(v - vr).max() < TOL
+    e.close()
+
+
+@pytest.mark.parametrize("rows,cols,ch,nb,n", [(6, 6, 64, 3, 1), (6, 6, 64, 3, 3), (6, 6, 64, 3, 4), (6, 6, 64, 3, 5),
+                                               (6, 6, 64, 3, 333), (3, 3, 64, 2, 257), (9, 9, 64, 2, 77),
+                                               (4, 2, 32, 2, 50), (6, 6, 128, 1, 19), (1, 1, 16, 1, 9)])
+def test_ragged_batches_vs_torch(rows, cols, ch, nb, n):
+    """Batch sizes around the samples-per-workgroup boundary; arbitrary float inputs."""
+    torch.manual_seed(rows * 31 + cols + ch + n)
+    m = nn_ref.ResNetZeroRef(rows, cols, ch, nb)
+    nn_ref.randomize_bn(m, 5)
+    e = engine_for(rows, cols, m, n_slots=128)
+    X = torch.randn(n, 3, rows + 1, cols + 1).numpy()
+    p, v = e.predict(X)
+    pr, vr = nn_ref.predict_sync(m, X)
+    assert np.abs(p - pr).max() < TOL, np.abs(p - pr).max()
+    assert np.abs(v - vr).max() < TOL, np.abs(v - vr).max()
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5)
+    e.close()
+
+
+def test_results_independent_of_batch_composition():
+    """Leaf-eval cache contract (utils/proxies.py:35-43): a sample's (p, v) must not
+    depend on what else is in the batch -- bit-identical alone and inside a large batch."""
+    torch.manual_seed(1)
+    m = nn_ref.ResNetZeroRef(6, 6, 64, 4)
+    nn_ref.randomize_bn(m, 5)
+    e = engine_for(6, 6, m, n_slots=256)
+    X = torch.randn(200, 3, 7, 7).numpy()
+    p, v = e.predict(X)
+    for i in (0, 3, 4, 77, 199):
+        pi, vi = e.predict(X[i:i + 1])
+        assert np.array_equal(pi[0], p[i]) and np.array_equal(vi[0], v[i])
+    perm = np.random.RandomState(0).permutation(200)
+    p2, v2 = e.predict(X[perm])
+    assert np.array_equal(p2, p[perm]) and np.array_equal(v2, v[perm])
+    e.close()
+
+
+def test_predict_before_commit_is_an_error():
+    from dotsboxesaz_amd import _lib
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(3, 3, 4, evaluator="resnet")
+    with pytest.raises(_lib.DbazError):
+        e.predict(np.zeros((1, 3, 4, 4), np.float32))
+    with pytest.raises(_lib.DbazError):
+        e.load_state_dict({"bn_input.weight": np.ones(3, np.float32)}, "resnet", 16, 1, 4, 8)  # incomplete
+    e.close()

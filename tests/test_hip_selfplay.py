@@ -1,0 +1,168 @@
+"""HIP self-play driver (device-side SelfPlay.play_game + get_datasets rows) vs the
+reference's golden games and the oracle -- rows D1-D3, B1."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from conftest import load_golden
+from test_oracle_selfplay import golden_games
+
+pytestmark = pytest.mark.gpu
+
+_G = load_golden("selfplay.npz")
+FORMULA_CASES = [str(c) for c in _G["cases"] if str(c) != "sp33_resnet"]
+
+
+def compare_rows(got, rows_slice, g, name):
+    r = rows_slice
+    assert np.array_equal(got["move"], g[name + "_move"][r])
+    assert np.array_equal(got["player"], g[name + "_player"][r])
+    assert np.array_equal(got["x"], g[name + "_x"][r])
+    assert np.array_equal(got["pi"].view(np.uint64), g[name + "_pi"][r].view(np.uint64))
+    assert np.array_equal(got["z"].astype(np.int64), g[name + "_z"][r])
+    st = np.stack([got["max_deepness"].astype(np.int32), got["tree_size"], got["terminal_count"]], axis=1)
+    assert np.array_equal(st, g[name + "_stats"][r])
+    assert np.array_equal(got["q_value"].view(np.uint32), g[name + "_q"][r].view(np.uint32))
+    assert np.array_equal(got["move_idx"], g[name + "_index"][r, 2])
+    assert np.array_equal(got["game_idx"], g[name + "_index"][r, 1])
+
+
+@pytest.mark.parametrize("name", FORMULA_CASES)
+@pytest.mark.parametrize("n_slots", [1, 4])
+def test_golden_games_teacher_forced(name, n_slots):
+    """The reference's sampled moves and Dirichlet vectors are injected; every row of
+    get_datasets must match bit for bit (n_slots=1 plays the games one after the other in
+    one slot, n_slots=4 concurrently)."""
+    from dotsboxesaz_amd.engine import Engine
+    g = _G
+    rows, cols, sims, a, c, reuse, n_games, _seed = g[name + "_cfg"]
+    temp = {int(k): float(v) for k, v in g[name + "_temp"]}
+    e = Engine(int(rows), int(cols), n_slots, mcts_num_read=int(sims), noise=(a, c), temperature=temp,
+               reuse_tree=bool(reuse), evaluator="uniform" if name == "sp33_uniform" else "formula")
+    games = golden_games(g, name)
+    for gi, gg in enumerate(games):
+        e.selfplay_script(gi, gg["moves"], gg["noise"])
+    e.selfplay_start(len(games), 0)
+    e.run()
+    cnt = e.counters()
+    assert cnt["games_finished"] == len(games) and cnt["error_slots"] == 0
+    got = e.fetch_samples()
+    all_rows = np.concatenate([gg["rows"] for gg in games])
+    assert np.array_equal(got["played"], np.concatenate([gg["moves"] for gg in games]))
+    compare_rows(got, all_rows, g, name)
+    e.close()
+
+
+@pytest.mark.parametrize("rows,cols,n_slots,n_games,sims,reuse", [(3, 3, 64, 200, 40, True), (3, 3, 32, 70, 30, False),
+                                                                  (6, 6, 48, 48, 60, True), (2, 3, 16, 40, 50, True)])
+def test_device_sampled_games_vs_oracle(rows, cols, n_slots, n_games, sims, reuse):
+    """Production path: moves sampled on the device (Philox), slots refilled as games end.
+    The oracle replays each game teacher-forced with the device's moves; all rows must be
+    bit-identical (noise off: numpy's Dirichlet stream cannot be matched on the device)."""
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(rows, cols, n_slots, mcts_num_read=sims, noise=(0.0, 0.0), reuse_tree=reuse, evaluator="formula",
+               seed=1234)
+    e.selfplay_start(n_games, 100)
+    e.run()
+    cnt = e.counters()
+    assert cnt["games_finished"] == n_games and cnt["active_slots"] == 0 and cnt["error_slots"] == 0
+    got = e.fetch_samples()
+    assert sorted(set(got["game_idx"])) == list(range(100, 100 + n_games))
+    d = O.dims(rows, cols)
+    pp = O.selfplay_params(sims, noise=(0.0, 0.0), reuse_tree=reuse)
+    ev = O.Evaluator(0)
+    total_search = 0
+    for gi in range(100, 100 + n_games):
+        r = np.nonzero(got["game_idx"] == gi)[0]
+        ref = O.play_game(d, pp, ev, forced_moves=got["played"][r])
+        total_search += ref["n_search"]
+        assert ref["n_rows"] == len(r)
+        assert np.array_equal(ref["move"], got["move"][r])
+        assert np.array_equal(ref["player"], got["player"][r])
+        assert np.array_equal(ref["x"], got["x"][r])
+        assert np.array_equal(ref["visits"], got["visits"][r])
+        assert np.array_equal(ref["pi"].view(np.uint64), got["pi"][r].view(np.uint64))
+        assert np.array_equal(ref["z"], got["z"][r].astype(np.int64))
+        assert np.array_equal(ref["q_value"].view(np.uint32), got["q_value"][r].view(np.uint32))
+        assert np.array_equal(ref["tree_size"], got["tree_size"][r])
+        assert np.array_equal(ref["terminal_count"], got["terminal_count"][r])
+        assert np.array_equal(ref["max_deepness"], got["max_deepness"][r].astype(np.int32))
+        # legality + scoring: replaying the moves reaches a finished game with the recorded winner
+        s = O.new_state(d)
+        for m in got["played"][r]:
+            O.play_(d, s, int(m))
+        assert O.get_result(s) in (0, 1)
+    assert cnt["expansions"] == total_search  # node-expansion counter == number of _search calls
+    e.close()
+
+
+def test_device_noise_is_a_valid_dirichlet_mix():
+    """With device-drawn noise the root priors stay a probability vector over the valid moves:
+    0.75*probs + 0.25*noise, noise >= 0, masked (mcts.py:219-226)."""
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(6, 6, 64, mcts_num_read=30, noise=(0.8, 0.25), evaluator="formula", seed=7)
+    e.set_positions(None)
+    e.search(30)
+    r = e.roots()
+    f = Engine(6, 6, 64, mcts_num_read=30, noise=(0.0, 0.0), evaluator="formula")
+    f.set_positions(None)
+    f.search(30)
+    base = f.roots()["priors"]
+    noise = (r["priors"] - 0.75 * base) / 0.25
+    st = e.root_states()
+    valid = e.rules_valid_moves(st)
+    assert (noise[~valid] == 0).all() and (noise >= -1e-12).all()
+    # the Dirichlet sample sums to 1 over ALL slots, so the valid part sums to <= 1 and is not degenerate
+    s = noise.sum(1)
+    assert (s <= 1 + 1e-9).all() and (s > 0.5).all()
+    assert np.abs(noise[0] - noise[1]).max() > 1e-3  # slots draw different vectors
+    e.close()
+    f.close()
+
+
+def test_resnet_selfplay_end_to_end():
+    """BASELINE config 1 shape (3x3, 25 sims, random-init ResNetZero) fully on the device:
+    legal finished games, consistent rows, and the first root's (p, v) equals predict()."""
+    import torch
+    from oracle import nn_ref
+    from dotsboxesaz_amd.engine import Engine
+    torch.manual_seed(0)
+    m = nn_ref.ResNetZeroRef(3, 3, 64, 4)
+    nn_ref.randomize_bn(m, 3)
+    e = Engine(3, 3, 16, mcts_num_read=25, noise=(0.8, 0.25), evaluator="resnet", seed=3)
+    e.load_state_dict(m.state_dict(), "resnet", 64, 4, 16, 8)
+    e.selfplay_start(32, 0)
+    e.run()
+    cnt = e.counters()
+    assert cnt["games_finished"] == 32 and cnt["error_slots"] == 0
+    got = e.fetch_samples()
+    d = O.dims(3, 3)
+    for gi in range(32):
+        r = np.nonzero(got["game_idx"] == gi)[0]
+        s = O.new_state(d)
+        for k, i in enumerate(r):
+            assert np.array_equal(got["x"][i], O.features(d, s).ravel())
+            assert got["player"][i] == s.to_play and got["move_idx"][i] == k
+            assert abs(got["pi"][i].sum() - 1) < 1e-12 and got["visits"][i][got["played"][i]] > 0
+            O.play_(d, s, int(got["played"][i]))
+        res = O.get_result(s)
+        assert res in (0, 1)
+        zexp = np.where(got["player"][r] == s.just_played, res, -res)
+        assert np.array_equal(got["z"][r], zexp)
+    e.close()
+
+
+def test_output_buffer_backpressure():
+    """A tiny finished-row buffer: finished games wait (PH_EMIT), run() drains and resumes;
+    nothing is lost or duplicated."""
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(3, 3, 8, mcts_num_read=20, evaluator="formula", seed=5, max_out_rows=30)
+    e.selfplay_start(24, 0)
+    e.run()
+    got = e.fetch_samples()
+    assert e.counters()["games_finished"] == 24
+    assert sorted(set(got["game_idx"])) == list(range(24))
+    for gi in range(24):
+        r = np.nonzero(got["game_idx"] == gi)[0]
+        assert np.array_equal(got["move_idx"][r], np.arange(len(r)))
+    e.close()
