@@ -1,0 +1,127 @@
+"""Host-side mirror of the reference's network interface (nn.py, dots_boxes_nn.py).
+
+`ResNetZero(params)` / `SimpleNN(params)` keep the reference's constructor, module tree
+and state_dict key names (so `torch.load(fn)['model_dict']` checkpoints load unchanged,
+nn.py:124-129), but they are WEIGHT CONTAINERS: the forward pass of the product runs in
+the HIP engine (`NeuralNetWrapper.predict_sync` -> dbaz_nn_predict).  Calling
+`forward()` on a container raises -- there is no torch/CPU fallback on the product path.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+
+def _get(d, k):
+    return d[k] if isinstance(d, dict) else getattr(d, k)
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, ch, k):
+        super().__init__()
+        self.conv1 = nn.Conv2d(ch, ch, k, padding=(k - 1) // 2)
+        self.bn1 = nn.BatchNorm2d(ch)
+        self.conv2 = nn.Conv2d(ch, ch, k, padding=(k - 1) // 2)
+        self.bn2 = nn.BatchNorm2d(ch)
+
+
+class _ResNet(nn.Module):
+    def __init__(self, in_channels, nb_channels, kernel_size, nb_blocks, n_groups=1, inner_channels=None,
+                 pad_layer0=True):
+        super().__init__()
+        if kernel_size != 3 or n_groups != 1 or inner_channels or not pad_layer0:
+            raise NotImplementedError("the HIP tower implements the shipped configuration: 3x3 kernels, "
+                                      "no groups, no inner conv (configuration.py:134-142)")
+        self.conv0 = nn.Conv2d(in_channels, nb_channels, 3, padding=1)
+        self.bn0 = nn.BatchNorm2d(nb_channels)
+        self.resblocks = nn.Sequential(*[_ResBlock(nb_channels, kernel_size) for _ in range(nb_blocks)])
+
+
+class _PolicyHead(nn.Module):
+    def __init__(self, in_channels, inner_channels, fc_in, nb_actions):
+        super().__init__()
+        self.conv0 = nn.Conv2d(in_channels, inner_channels, kernel_size=(1, 1))
+        self.bn0 = nn.BatchNorm2d(inner_channels)
+        self.fc = nn.Linear(fc_in, nb_actions)
+
+
+class _ValueHead(nn.Module):
+    def __init__(self, in_channels, inner_channels, fc_in, fc_inner):
+        super().__init__()
+        self.conv0 = nn.Conv2d(in_channels, inner_channels, kernel_size=(1, 1))
+        self.bn0 = nn.BatchNorm2d(inner_channels)
+        self.fc0 = nn.Linear(fc_in, fc_inner)
+        self.fc1 = nn.Linear(fc_inner, 1)
+
+
+class ResNetZero(nn.Module):
+    """Reference: nn.py:108-129.  params.nn.model_parameters.{resnet,value_head,policy_head}."""
+
+    kind = "resnet"
+
+    def __init__(self, params):
+        super().__init__()
+        self.params = params
+        mp = _get(_get(params, "nn"), "model_parameters")
+        rp, vp, pp = dict(_get(mp, "resnet")), dict(_get(mp, "value_head")), dict(_get(mp, "policy_head"))
+        self.bn_input = nn.BatchNorm2d(rp["in_channels"])
+        self.resnet = _ResNet(**rp)
+        self.value_head = _ValueHead(**vp)
+        self.policy_head = _PolicyHead(**pp)
+        self.shape = dict(channels=rp["nb_channels"], blocks=rp["nb_blocks"], head_channels=pp["inner_channels"],
+                          value_fc=vp["fc_inner"])
+        if vp["inner_channels"] != pp["inner_channels"]:
+            raise NotImplementedError("policy and value heads must use the same inner_channels")
+
+    def forward(self, x):
+        raise RuntimeError("ResNetZero is a weight container on this path: evaluate through "
+                           "NeuralNetWrapper.predict_sync (HIP engine); there is no torch fallback")
+
+    def load_parameters(self, generation, to_device=None):
+        fn = _get(_get(self.params, "nn"), "chkpts_filename").format(generation)
+        self.load_state_dict(torch.load(fn, map_location="cpu", weights_only=True)["model_dict"])
+
+
+def resnet_params(rows, cols, channels=64, blocks=20, head_channels=16, value_fc=8):
+    """The shipped `resnet` configuration (configuration.py:134-156) resized to a rows x cols board."""
+    H, W = rows + 1, cols + 1
+    return {"nn": {"model_parameters": {
+        "resnet": {"pad_layer0": True, "in_channels": 3, "nb_channels": channels, "inner_channels": None,
+                   "kernel_size": 3, "nb_blocks": blocks, "n_groups": 1},
+        "policy_head": {"in_channels": channels, "inner_channels": head_channels, "fc_in": head_channels * H * W,
+                        "nb_actions": 2 * H * W},
+        "value_head": {"in_channels": channels, "inner_channels": head_channels, "fc_in": head_channels * H * W,
+                       "fc_inner": value_fc}}, "pytorch_device": "cuda:0", "chkpts_filename": "model_gen{}.pt"}}
+
+
+class NeuralNetWrapper:
+    """Reference: nn.py:145-173 -- predict_sync(X [n,3,H,W]) -> (softmax p [n,A], v [n,1]) numpy float32."""
+
+    def __init__(self, model, params=None, engine=None, rows=None, cols=None, n_slots=4096, device=0):
+        from .engine import Engine
+        self.params = params
+        self.engine = engine
+        self._own = engine is None
+        if engine is None:
+            if rows is None:
+                raise ValueError("rows/cols (board size) required when no engine is given")
+            self.engine = Engine(rows, cols, n_slots, evaluator=model.kind if model is not None else "resnet",
+                                 device=device)
+        self.model = None
+        if model is not None:
+            self.set_model(model)
+
+    def set_model(self, model):
+        self.model = model
+        self.engine.load_state_dict(model.state_dict(), model.kind, **model.shape)
+
+    def predict_sync(self, X):
+        return self.engine.predict(np.asarray(X, dtype=np.float32))
+
+    async def predict(self, X):
+        return self.predict_sync(X)
+
+    async def predict_from_game(self, game_state):
+        return await self.predict([game_state.get_features()])
+
+    async def __call__(self, X):
+        return await self.predict(X)

@@ -1,0 +1,186 @@
+"""Host-side mirror of the reference's self-play driver contract (self_play.py).
+
+    generate_games(hdf_file_name, generation, nn_class, n_games, params, ...)   self_play.py:291-306
+    SelfPlay(nn, params).play_games(...) / get_datasets(generation)             self_play.py:19-156
+
+The games themselves run on the GPU (dotsboxesaz_amd.engine.Engine): thousands of concurrent
+games, one sequential search per game (the reference's max_async_searches=1 semantics), slots
+refilled as games finish.  This module only shapes configuration in and DataFrames out, shards
+game indices over ranks and all-gathers the replay rows over RCCL at iteration end.
+"""
+import time
+
+import numpy as np
+
+
+def _get(d, k, default=None):
+    if d is None:
+        return default
+    if isinstance(d, dict):
+        return d.get(k, default)
+    return getattr(d, k, default)
+
+
+def shard_games(n_games, world_size, rank):
+    """Contiguous game-index range of `rank` (np.array_split semantics, self_play.py:294)."""
+    base, extra = divmod(int(n_games), int(world_size))
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def engine_kwargs_from_params(params):
+    """Pull the hot-path knobs out of a reference-style params dict (configuration.py:82-100)."""
+    sp = _get(params, "self_play")
+    m = _get(sp, "mcts")
+    noise = _get(sp, "noise", [0.0, 0.0])
+    return dict(mcts_num_read=int(_get(m, "mcts_num_read", 800)), cpuct=tuple(_get(m, "mcts_cpuct", (1.25, 19652))),
+                noise=(float(noise[0]), float(noise[1])), temperature=dict(_get(m, "temperature", {0: 1.0})),
+                reuse_tree=bool(_get(sp, "reuse_mcts_tree", True)))
+
+
+def samples_to_dataframe(s, generation, rows, cols, with_features=True):
+    """SelfPlay.get_datasets schema (self_play.py:95-156): index (generation, game_idx, move_idx);
+    columns move i16, player i8, x_* i16, pi_* f64, z i64, max_deepness i16, tree_size i32,
+    terminal_count i32, q_value f32."""
+    import pandas as pd
+    n = len(s["move"])
+    A = s["pi"].shape[1]
+    F = s["x"].shape[1]
+    if isinstance(generation, (list, tuple)):
+        gen = np.where(s["player"] == 0, generation[0], generation[1]).astype(np.int16)
+    else:
+        gen = np.full(n, generation, dtype=np.int16)
+    cols_ = {"generation": gen, "game_idx": s["game_idx"].astype(np.int16), "move_idx": s["move_idx"].astype(np.int16),
+             "move": s["move"].astype(np.int16), "player": s["player"].astype(np.int8)}
+    df = pd.DataFrame(cols_)
+    parts = [df]
+    if with_features:
+        parts.append(pd.DataFrame(s["x"].astype(np.int16), columns=["x_%d" % i for i in range(F)]))
+    parts.append(pd.DataFrame(s["pi"].astype(np.float64), columns=["pi_%d" % i for i in range(A)]))
+    parts.append(pd.DataFrame({"z": s["z"].astype(np.int64)}))
+    parts.append(pd.DataFrame({"max_deepness": s["max_deepness"].astype(np.int16), "tree_size": s["tree_size"].astype(np.int32),
+                               "terminal_count": s["terminal_count"].astype(np.int32),
+                               "q_value": s["q_value"].astype(np.float32)}))
+    df = pd.concat(parts, axis=1)
+    df.set_index(["generation", "game_idx", "move_idx"], inplace=True)
+    return df
+
+
+class SelfPlay:
+    """Reference: self_play.py:19-156.  `nn` is a dotsboxesaz_amd.nn.NeuralNetWrapper (its engine
+    plays the games) or an Engine whose evaluator is already configured."""
+
+    def __init__(self, nn, params):
+        self.params = params
+        self.engine = getattr(nn, "engine", nn)
+        self.samples = None
+
+    def play_games_sync(self, games_idxs):
+        idx = np.asarray(list(games_idxs), dtype=np.int64)
+        if len(idx) == 0:
+            return
+        if not np.array_equal(idx, np.arange(idx[0], idx[0] + len(idx))):
+            raise ValueError("game indices must be a contiguous range")
+        self.engine.selfplay_start(len(idx), int(idx[0]))
+        self.engine.run()
+        got = self.engine.fetch_samples()
+        self.samples = got if self.samples is None else {k: np.concatenate([self.samples[k], got[k]]) for k in got}
+
+    async def play_games(self, game_state, games_idxs, show_progress=False):
+        self.play_games_sync(games_idxs)
+
+    def get_datasets(self, generation, with_features=True):
+        e = self.engine
+        return samples_to_dataframe(self.samples, generation, e.rows, e.cols, with_features)
+
+
+def write_dataset(file_name, key, df):
+    """utils.write_to_hdf (utils/utils.py:94-96): append to an HDFStore table; parquet when the
+    file name says so (pytables is not part of this image)."""
+    if str(file_name).endswith(".parquet"):
+        df.reset_index().to_parquet(file_name)
+        return
+    import pandas as pd
+    with pd.HDFStore(file_name, mode="a") as store:
+        store.append(key, df, format="table")
+
+
+def generate_games(hdf_file_name, generation, nn_class, n_games, params, n_workers=None, games_per_workers=10,
+                   rows=None, cols=None, n_slots=None, device=0, dist=None):
+    """Reference: self_play.generate_games (self_play.py:291-306) called from coach.selfplay
+    (coach.py:27-29).  Plays n_games with generation-1's weights (random init for generation 0,
+    self_play.py:187-190) and appends the samples (+ `training` = 0) to key "fresh".
+    With torch.distributed initialised (one process per GPU) the game indices are sharded over
+    the ranks and the rows all-gathered; rank 0 writes."""
+    from .engine import Engine
+    game = _get(params, "game")
+    if rows is None:
+        dims = _get(game, "dims") or getattr(_get(game, "clazz"), "BOARD_DIM", (3, 3))
+        rows, cols = int(dims[0]), int(dims[1])
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    first, count = shard_games(n_games, world, rank)
+    n_slots = n_slots or max(1, min(count, 8192))
+    model = nn_class(params)
+    if generation != 0:
+        model.load_parameters(generation - 1)
+    eng = Engine(rows, cols, n_slots, evaluator=model.kind, device=device, seed=generation * 1000003 + rank,
+                 **engine_kwargs_from_params(params))
+    eng.load_state_dict(model.state_dict(), model.kind, **model.shape)
+    sp = SelfPlay(eng, params)
+    sp.play_games_sync(range(first, first + count))
+    if dist is not None and world > 1:
+        gather_replay(eng, dist)  # device-resident rows over RCCL; the host copy below is what gets written
+    df = sp.get_datasets(generation, True)
+    df["training"] = np.zeros(len(df.index), dtype=np.int8)
+    if hdf_file_name is not None and rank == 0:
+        write_dataset(hdf_file_name, "fresh", df)
+    eng.close()
+    return df
+
+
+# ---------------------------------------------------------------------------------------
+# multi-GPU: replay all-gather over RCCL (replaces the HDF-append-under-lock exchange,
+# self_play.py:264-265).  Fixed-stride packed rows (DESIGN.md "replay row").
+# ---------------------------------------------------------------------------------------
+class _DevBuf:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+
+def all_gather_rows(rows, dist):
+    """rows: uint8 tensor [n_i, row_bytes] (any device).  Returns (uint8 [sum n_i, row_bytes], counts)."""
+    import torch
+    world = dist.get_world_size()
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    padded = torch.zeros((mx, rows.shape[1]), dtype=torch.uint8, device=rows.device)
+    padded[: rows.shape[0]] = rows
+    out = torch.empty((world * mx, rows.shape[1]), dtype=torch.uint8, device=rows.device)
+    dist.all_gather_into_tensor(out, padded)
+    keep = torch.cat([out[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
+    return keep, counts
+
+
+def gather_replay(engine, dist, synthetic_rows=0):
+    """All-gather the finished rows that sit in HBM (dbaz_replay_rows_dev).  Returns
+    (total rows, milliseconds).  synthetic_rows > 0 pads every rank's shard to that many rows
+    (benchmarking the exchange before games have finished)."""
+    import torch
+    ptr, n, rb = engine.replay_rows_dev()
+    dev = torch.device("cuda", engine.cfg.device)
+    if n > 0:
+        rows = torch.as_tensor(_DevBuf(ptr, n * rb), device=dev).view(n, rb)
+    else:
+        rows = torch.zeros((0, rb), dtype=torch.uint8, device=dev)
+    if synthetic_rows > n:
+        rows = torch.cat([rows, torch.zeros((synthetic_rows - n, rb), dtype=torch.uint8, device=dev)], dim=0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    allrows, counts = all_gather_rows(rows, dist)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    return int(sum(counts)), ms
