@@ -55,7 +55,7 @@ struct NNState {
     float *wp = nullptr, *bp = nullptr;         // policy FC transposed [hc*HW][A], [A]
     float *wv0 = nullptr, *bv0 = nullptr;       // value FC0 transposed [hc*HW][vf], [vf]
     float *wv1 = nullptr, *bv1 = nullptr;       // [vf], [1]
-    int S = 1, NT = 1;                          // samples / position tiles per conv workgroup
+    int S = 1, NT = 1, NTT = 13;                // samples / position tiles per conv workgroup (NTT: compiled tile count)
     size_t conv_lds = 0;
 };
 
@@ -100,15 +100,22 @@ __global__ void __launch_bounds__(256) k_conv0(Geo g, int C, const float *__rest
 // conv3x3 C -> C on MFMA (f32 exact)
 // ------------------------------------------------------------------------------------
 // flags: 1 = add residual before ReLU; 2 = ReLU; 4 = post affine after ReLU (SimpleNN)
-template <int C>
-__global__ void __launch_bounds__(CONV_THREADS) k_conv3x3(Geo g, int S, int NT, const int32_t *n_dev,
-                                                          const float *__restrict__ in, const float *__restrict__ wpk,
-                                                          const float *__restrict__ bias, const float *__restrict__ res,
-                                                          const float *__restrict__ post_s, const float *__restrict__ post_t,
-                                                          float *__restrict__ out, int flags)
+//
+// NTT = compile-time number of 16-row position tiles (rows >= R are computed on the zero row
+// and dropped).  The (tap, 16-cin chunk) loop is software pipelined by hand: the weight
+// fragment and the NTT activation fragments of step i+1 are in flight while the 4*NTT MFMAs
+// of step i issue.  LDS is indexed in float4 units so that every activation read is one
+// ds_read_b128.
+template <int C, int NTT>
+__global__ void __launch_bounds__(CONV_THREADS, 2) k_conv3x3(Geo g, int S, const int32_t *n_dev,
+                                                             const float *__restrict__ in, const float *__restrict__ wpk,
+                                                             const float *__restrict__ bias, const float *__restrict__ res,
+                                                             const float *__restrict__ post_s, const float *__restrict__ post_t,
+                                                             float *__restrict__ out, int flags)
 {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int STRIDE = C + 8;    // dwords per LDS row
+    constexpr int S4 = STRIDE / 4;   // float4 per LDS row
     constexpr int KC = C / 16;       // 16-cin chunks per tap
     const int n = *n_dev;
     const int s0 = blockIdx.x * S;
@@ -117,87 +124,106 @@ __global__ void __launch_bounds__(CONV_THREADS) k_conv3x3(Geo g, int S, int NT, 
     const int ns = min(S, n - s0);
     const int R = ns * HW;           // valid rows in this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 *lds4 = reinterpret_cast<f32x4 *>(lds);
     // ---- stage the samples' activations: rows [0, R) ; row S*HW is the shared zero row
     const int zrow = S * HW;
     {
-        const float4 *src = reinterpret_cast<const float4 *>(in + (size_t)s0 * HW * C);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)s0 * HW * C);
         const int nv = R * (C / 4);
         for (int i = tid; i < nv; i += CONV_THREADS) {
             int r = i / (C / 4), c4 = i - r * (C / 4);
-            float4 v = src[i];
-            *reinterpret_cast<float4 *>(lds + r * STRIDE + c4 * 4) = v;
+            lds4[r * S4 + c4] = src[i];
         }
-        for (int i = tid; i < STRIDE; i += CONV_THREADS) lds[zrow * STRIDE + i] = 0.0f;
+        if (tid < S4) lds4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     const int jrow = lane & 15, gq = lane >> 4;
-    // per position tile: (y, x) of this lane's row, or invalid
-    int ty[MAXT], tx[MAXT];
+    // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
+    // (0 for rows >= R: they read the zero row for every tap)
+    int vm[NTT];
 #pragma unroll
-    for (int t = 0; t < MAXT; t++) {
+    for (int t = 0; t < NTT; t++) {
         int row = t * 16 + jrow;
-        bool ok = (t < NT) && (row < R);
-        int pos = row % HW;
-        ty[t] = ok ? pos / W : -1000;
-        tx[t] = pos % W;
-    }
-    for (int ct = wave; ct < C / 16; ct += CONV_THREADS / 64) {
-        f32x4 acc[MAXT];
+        int pos = row % HW, y = pos / W, x = pos - y * W;
+        int m = 0;
 #pragma unroll
-        for (int t = 0; t < MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float4 *wbase = reinterpret_cast<const float4 *>(wpk) + (size_t)ct * 9 * KC * 64 + lane;
         for (int tap = 0; tap < 9; tap++) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            int addr[MAXT];
+            int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
+        }
+        vm[t] = row < R ? m : 0;
+    }
+    // LDS addresses in float4 units.  Tile t's constant t*16*S4 is folded into the ds_read
+    // immediate, so the invalid alternative is the zero row minus that constant.
+    const int rowbase = jrow * S4 + gq;
+    const int zbase = zrow * S4 + gq;
+    for (int ct = wave; ct < C / 16; ct += CONV_THREADS / 64) {
+        f32x4 acc[NTT];
 #pragma unroll
-            for (int t = 0; t < MAXT; t++) {
-                int yy = ty[t] + dy, xx = tx[t] + dx;
-                bool ok = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
-                int row = t * 16 + jrow + dy * W + dx;
-                addr[t] = (ok ? row : zrow) * STRIDE + gq * 4;
-            }
-#pragma unroll 2
+        for (int t = 0; t < NTT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 *wbase = reinterpret_cast<const f32x4 *>(wpk) + (size_t)ct * 9 * KC * 64 + lane;
+        int addr[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; t++) addr[t] = (vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase - t * 16 * S4;
+        f32x4 a_cur = wbase[0];
+        f32x4 b_cur[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; t++) b_cur[t] = lds4[addr[t] + t * 16 * S4];
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
             for (int kc = 0; kc < KC; kc++) {
-                const float4 a = wbase[(size_t)(tap * KC + kc) * 64];
-                f32x4 bfr[MAXT];
+                // ---- prefetch step i+1 (the first chunk of the next tap after the last chunk)
+                f32x4 a_nxt, b_nxt[NTT];
+                if (kc == KC - 1) {
+                    const int tn = tap + 1;
+                    const int off = ((tn / 3 - 1) * W + (tn % 3 - 1)) * S4;
 #pragma unroll
-                for (int t = 0; t < MAXT; t++)
-                    if (t < NT) bfr[t] = *reinterpret_cast<const f32x4 *>(lds + addr[t] + kc * 16);
+                    for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> tn) & 1) ? rowbase + off : zbase - t * 16 * S4;
+                    a_nxt = wbase[(size_t)(tn < 9 ? tn * KC : 0) * 64];
 #pragma unroll
-                for (int t = 0; t < MAXT; t++)
-                    if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bfr[t][0], acc[t], 0, 0, 0);
+                    for (int t = 0; t < NTT; t++) b_nxt[t] = lds4[addr[t] + t * 16 * S4];
+                } else {
+                    a_nxt = wbase[(size_t)(tap * KC + kc + 1) * 64];
 #pragma unroll
-                for (int t = 0; t < MAXT; t++)
-                    if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bfr[t][1], acc[t], 0, 0, 0);
+                    for (int t = 0; t < NTT; t++) b_nxt[t] = lds4[addr[t] + t * 16 * S4 + (kc + 1) * 4];
+                }
+                // keep the prefetch ABOVE the MFMAs: without the pin hipcc sinks the loads to their
+                // first use and the wave stalls on L2/LDS latency every step
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- 4 * NTT MFMAs of step i
 #pragma unroll
-                for (int t = 0; t < MAXT; t++)
-                    if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bfr[t][2], acc[t], 0, 0, 0);
+                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0], b_cur[t][0], acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < MAXT; t++)
-                    if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bfr[t][3], acc[t], 0, 0, 0);
+                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1], b_cur[t][1], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[2], b_cur[t][2], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[3], b_cur[t][3], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a_cur = a_nxt;
+#pragma unroll
+                for (int t = 0; t < NTT; t++) b_cur[t] = b_nxt[t];
             }
         }
         // ---- epilogue: lane holds couts ct*16 + 4*gq .. +3 of position row t*16 + jrow
         const int co = ct * 16 + gq * 4;
-        const float4 bv = *reinterpret_cast<const float4 *>(bias + co);
-        float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + co);
+        f32x4 ps = (f32x4){1.f, 1.f, 1.f, 1.f}, pt = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (flags & 4) {
-            ps = *reinterpret_cast<const float4 *>(post_s + co);
-            pt = *reinterpret_cast<const float4 *>(post_t + co);
+            ps = *reinterpret_cast<const f32x4 *>(post_s + co);
+            pt = *reinterpret_cast<const f32x4 *>(post_t + co);
         }
 #pragma unroll
-        for (int t = 0; t < MAXT; t++) {
+        for (int t = 0; t < NTT; t++) {
             int row = t * 16 + jrow;
-            if (t < NT && row < R) {
+            if (row < R) {
                 size_t off = ((size_t)s0 * HW + row) * C + co;
-                float4 v = make_float4(acc[t][0] + bv.x, acc[t][1] + bv.y, acc[t][2] + bv.z, acc[t][3] + bv.w);
-                if (flags & 1) {
-                    const float4 r4 = *reinterpret_cast<const float4 *>(res + off);
-                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-                }
-                if (flags & 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (flags & 4) { v.x = v.x * ps.x + pt.x; v.y = v.y * ps.y + pt.y; v.z = v.z * ps.z + pt.z; v.w = v.w * ps.w + pt.w; }
-                *reinterpret_cast<float4 *>(out + off) = v;
+                f32x4 v = acc[t] + bv;
+                if (flags & 1) v += *reinterpret_cast<const f32x4 *>(res + off);
+                if (flags & 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (flags & 4) v = v * ps + pt;
+                *reinterpret_cast<f32x4 *>(out + off) = v;
             }
         }
     }
@@ -414,6 +440,39 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
     return true;
 }
 
+// launches (or, with attr_only, raises the dynamic-LDS limit of) the instantiation for (C, NTT)
+template <int C, int NTT>
+static hipError_t conv_inst(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, const ConvLayer &L,
+                            const float *res, float *out, int flags, bool attr_only)
+{
+    if (attr_only)
+        return hipFuncSetAttribute((const void *)k_conv3x3<C, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
+    const int grid = (max_n + nn->S - 1) / nn->S;
+    hipLaunchKernelGGL((k_conv3x3<C, NTT>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, n_dev, in, L.w, L.bias,
+                       res, L.post_s, L.post_t, out, flags);
+    return hipSuccess;
+}
+template <int C>
+static hipError_t conv_inst_c(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, const ConvLayer &L,
+                              const float *res, float *out, int flags, bool attr_only)
+{
+    switch (nn->NTT) {
+    case 4: return conv_inst<C, 4>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
+    case 8: return conv_inst<C, 8>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
+    default: return conv_inst<C, 13>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
+    }
+}
+static hipError_t conv_dispatch(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, const ConvLayer &L,
+                                const float *res, float *out, int flags, bool attr_only)
+{
+    switch (nn->C) {
+    case 16: return conv_inst_c<16>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
+    case 32: return conv_inst_c<32>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
+    case 64: return conv_inst_c<64>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
+    default: return conv_inst_c<128>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
+    }
+}
+
 int nn_commit(NNState *nn, hipStream_t s, std::string &err)
 {
     (void)s;
@@ -505,14 +564,8 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     nn->NT = (S * HW + 15) / 16;
     if (nn->NT > MAXT) { err = "board too large for the conv tile"; return DBAZ_EINVAL; }
     nn->conv_lds = (size_t)(S * HW + 1) * (C + 8) * 4;
-    hipError_t he = hipSuccess;
-    const int lds_i = (int)nn->conv_lds;
-    switch (C) {
-    case 16: he = hipFuncSetAttribute((const void *)k_conv3x3<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_i); break;
-    case 32: he = hipFuncSetAttribute((const void *)k_conv3x3<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_i); break;
-    case 64: he = hipFuncSetAttribute((const void *)k_conv3x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_i); break;
-    case 128: he = hipFuncSetAttribute((const void *)k_conv3x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_i); break;
-    }
+    nn->NTT = nn->NT > 8 ? 13 : (nn->NT > 4 ? 8 : 4);
+    hipError_t he = conv_dispatch(nn, nullptr, nullptr, 0, nullptr, ConvLayer(), nullptr, nullptr, 0, true);
     if (he != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); return DBAZ_EDEVICE; }
     size_t hl = ((size_t)2 * hc * (C + 1) + (size_t)HW * (C + 1)) * 4;
     if (hl > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_head_conv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl);
@@ -523,13 +576,7 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
 static void launch_conv(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, const ConvLayer &L,
                         const float *res, float *out, int flags)
 {
-    const int grid = (max_n + nn->S - 1) / nn->S;
-    switch (nn->C) {
-    case 16: hipLaunchKernelGGL(k_conv3x3<16>, dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->NT, n_dev, in, L.w, L.bias, res, L.post_s, L.post_t, out, flags); break;
-    case 32: hipLaunchKernelGGL(k_conv3x3<32>, dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->NT, n_dev, in, L.w, L.bias, res, L.post_s, L.post_t, out, flags); break;
-    case 64: hipLaunchKernelGGL(k_conv3x3<64>, dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->NT, n_dev, in, L.w, L.bias, res, L.post_s, L.post_t, out, flags); break;
-    case 128: hipLaunchKernelGGL(k_conv3x3<128>, dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->NT, n_dev, in, L.w, L.bias, res, L.post_s, L.post_t, out, flags); break;
-    }
+    (void)conv_dispatch(nn, s, n_dev, max_n, in, L, res, out, flags, false);
 }
 
 void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *list_dev, const int32_t *n_dev, int max_n,
