@@ -156,7 +156,7 @@ def main():
     if rank == 0:
         HW = (rows + 1) * (cols + 1)
         conv_flops = 2.0 * HW * 9 * args.channels * args.channels  # per sample per tower conv launch
-        launches = 2 * args.blocks * args.steps
+        launches = args.steps  # one fused-tower launch per step (all 2*blocks conv layers)
         out = {
             "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt_max, "unit": "expansions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
@@ -183,10 +183,10 @@ def main():
         if args.evaluator == "resnet" and c1["ms_nn_tower"] > 0:
             ach = evals * conv_flops * 2 * args.blocks / (c1["ms_nn_tower"] * 1e-3) / 1e12
             peak = F32_MFMA_PEAK_TFLOPS if args.precision == 0 else F16_MFMA_PEAK_TFLOPS / 3.0
-            out["roofline"] = {"bound": "mfma", "kernel": "k_conv3x3<%d>" % args.channels, "achieved": ach, "peak": peak,
+            out["roofline"] = {"bound": "mfma", "kernel": "k_tower_%s<%d> (2*%d conv3x3 layers fused, LDS-resident)" % ("f32" if args.precision == 0 else "f16x3", args.channels, args.blocks), "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                                "avg_launch_us": 1e3 * c1["ms_nn_tower"] / launches,
-                               "flops_per_launch": evals / args.steps * conv_flops,
+                               "flops_per_launch": evals / args.steps * conv_flops * 2 * args.blocks,
                                "tower_ms_per_step": c1["ms_nn_tower"] / args.steps,
                                "tree_and_heads_ms_per_step": (c1["ms_total"] - c1["ms_nn_tower"]) / args.steps}
         else:

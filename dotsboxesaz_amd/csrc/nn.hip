@@ -46,10 +46,10 @@ struct NNState {
     std::map<std::string, std::vector<float>> sd;
     // device
     std::vector<void *> allocs;
-    float *actA = nullptr, *actB = nullptr, *actC = nullptr;
+    float *actA = nullptr, *actB = nullptr;
     float *in_s = nullptr, *in_t = nullptr;     // bn_input affine [3]
     float *w0 = nullptr, *b0 = nullptr;         // conv0 [9][3][C], [C]
-    std::vector<ConvLayer> tower;               // 2*blocks
+    float *tw = nullptr, *tb = nullptr;         // tower: packed weights [2*blocks][C*C*9], bias [2*blocks][C]
     float *hw = nullptr, *hb = nullptr;         // head conv1x1: [2*hc][C], [2*hc]
     float *hact = nullptr;                      // [batch][2][hc*HW]
     float *wp = nullptr, *bp = nullptr;         // policy FC transposed [hc*HW][A], [A]
@@ -99,64 +99,22 @@ __global__ void __launch_bounds__(256) k_conv0(Geo g, int C, const float *__rest
 // ------------------------------------------------------------------------------------
 // conv3x3 C -> C on MFMA (f32 exact)
 // ------------------------------------------------------------------------------------
-// flags: 1 = add residual before ReLU; 2 = ReLU; 4 = post affine after ReLU (SimpleNN)
-//
-// NTT = compile-time number of 16-row position tiles (rows >= R are computed on the zero row
-// and dropped).  The (tap, 16-cin chunk) loop is software pipelined by hand: the weight
-// fragment and the NTT activation fragments of step i+1 are in flight while the 4*NTT MFMAs
-// of step i issue.  LDS is indexed in float4 units so that every activation read is one
-// ds_read_b128.
+// One 3x3 conv layer, LDS -> LDS, for the S samples a workgroup owns (device function of the
+// fused tower kernel).  NTT = compile-time number of 16-row position tiles (rows >= R read the
+// zero row for every tap and are never written).  The (tap, 16-cin chunk) loop is software
+// pipelined by hand: the weight fragment (L2 -> registers) and the NTT activation fragments
+// (ds_read_b128) of step i+1 are in flight while the 4*NTT MFMAs of step i issue; a
+// sched_barrier keeps hipcc from sinking the prefetch to its first use.
+// residual != 0: dst already holds the block input x; the layer writes relu(conv + bias + x)
+// in place (every element is read and written by the same lane).
 template <int C, int NTT>
-__global__ void __launch_bounds__(CONV_THREADS, 2) k_conv3x3(Geo g, int S, const int32_t *n_dev,
-                                                             const float *__restrict__ in, const float *__restrict__ wpk,
-                                                             const float *__restrict__ bias, const float *__restrict__ res,
-                                                             const float *__restrict__ post_s, const float *__restrict__ post_t,
-                                                             float *__restrict__ out, int flags)
+__device__ __forceinline__ void conv_lds_f32(const f32x4 *__restrict__ src4, f32x4 *dst4, const float *__restrict__ wpk,
+                                             const float *__restrict__ bias, const int (&vm)[NTT], int rowbase, int zbase,
+                                             int W, int R, int wave, int lane, int residual)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int STRIDE = C + 8;    // dwords per LDS row
-    constexpr int S4 = STRIDE / 4;   // float4 per LDS row
+    constexpr int S4 = (C + 8) / 4;  // float4 per LDS row
     constexpr int KC = C / 16;       // 16-cin chunks per tap
-    const int n = *n_dev;
-    const int s0 = blockIdx.x * S;
-    if (s0 >= n) return;
-    const int HW = g.HW, W = g.W, H = g.H;
-    const int ns = min(S, n - s0);
-    const int R = ns * HW;           // valid rows in this workgroup
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    f32x4 *lds4 = reinterpret_cast<f32x4 *>(lds);
-    // ---- stage the samples' activations: rows [0, R) ; row S*HW is the shared zero row
-    const int zrow = S * HW;
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)s0 * HW * C);
-        const int nv = R * (C / 4);
-        for (int i = tid; i < nv; i += CONV_THREADS) {
-            int r = i / (C / 4), c4 = i - r * (C / 4);
-            lds4[r * S4 + c4] = src[i];
-        }
-        if (tid < S4) lds4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
     const int jrow = lane & 15, gq = lane >> 4;
-    // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
-    // (0 for rows >= R: they read the zero row for every tap)
-    int vm[NTT];
-#pragma unroll
-    for (int t = 0; t < NTT; t++) {
-        int row = t * 16 + jrow;
-        int pos = row % HW, y = pos / W, x = pos - y * W;
-        int m = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
-        }
-        vm[t] = row < R ? m : 0;
-    }
-    // LDS addresses in float4 units.  Tile t's constant t*16*S4 is folded into the ds_read
-    // immediate, so the invalid alternative is the zero row minus that constant.
-    const int rowbase = jrow * S4 + gq;
-    const int zbase = zrow * S4 + gq;
     for (int ct = wave; ct < C / 16; ct += CONV_THREADS / 64) {
         f32x4 acc[NTT];
 #pragma unroll
@@ -168,7 +126,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) k_conv3x3(Geo g, int S, const
         f32x4 a_cur = wbase[0];
         f32x4 b_cur[NTT];
 #pragma unroll
-        for (int t = 0; t < NTT; t++) b_cur[t] = lds4[addr[t] + t * 16 * S4];
+        for (int t = 0; t < NTT; t++) b_cur[t] = src4[addr[t] + t * 16 * S4];
 #pragma unroll 1
         for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
@@ -182,14 +140,12 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) k_conv3x3(Geo g, int S, const
                     for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> tn) & 1) ? rowbase + off : zbase - t * 16 * S4;
                     a_nxt = wbase[(size_t)(tn < 9 ? tn * KC : 0) * 64];
 #pragma unroll
-                    for (int t = 0; t < NTT; t++) b_nxt[t] = lds4[addr[t] + t * 16 * S4];
+                    for (int t = 0; t < NTT; t++) b_nxt[t] = src4[addr[t] + t * 16 * S4];
                 } else {
                     a_nxt = wbase[(size_t)(tap * KC + kc + 1) * 64];
 #pragma unroll
-                    for (int t = 0; t < NTT; t++) b_nxt[t] = lds4[addr[t] + t * 16 * S4 + (kc + 1) * 4];
+                    for (int t = 0; t < NTT; t++) b_nxt[t] = src4[addr[t] + t * 16 * S4 + (kc + 1) * 4];
                 }
-                // keep the prefetch ABOVE the MFMAs: without the pin hipcc sinks the loads to their
-                // first use and the wave stalls on L2/LDS latency every step
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- 4 * NTT MFMAs of step i
 #pragma unroll
@@ -207,24 +163,85 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) k_conv3x3(Geo g, int S, const
             }
         }
         // ---- epilogue: lane holds couts ct*16 + 4*gq .. +3 of position row t*16 + jrow
-        const int co = ct * 16 + gq * 4;
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + co);
-        f32x4 ps = (f32x4){1.f, 1.f, 1.f, 1.f}, pt = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (flags & 4) {
-            ps = *reinterpret_cast<const f32x4 *>(post_s + co);
-            pt = *reinterpret_cast<const f32x4 *>(post_t + co);
-        }
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + ct * 16 + gq * 4);
 #pragma unroll
         for (int t = 0; t < NTT; t++) {
-            int row = t * 16 + jrow;
+            const int row = t * 16 + jrow;
             if (row < R) {
-                size_t off = ((size_t)s0 * HW + row) * C + co;
+                const int o4 = row * S4 + ct * 4 + gq;
                 f32x4 v = acc[t] + bv;
-                if (flags & 1) v += *reinterpret_cast<const f32x4 *>(res + off);
-                if (flags & 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                if (flags & 4) v = v * ps + pt;
-                *reinterpret_cast<f32x4 *>(out + off) = v;
+                if (residual) v += dst4[o4];
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                dst4[o4] = v;
             }
+        }
+    }
+}
+
+// The whole residual tower in ONE launch: the S samples of a workgroup stay in LDS (two
+// ping-pong activation images of (S*HW+1) rows x (C+8) dwords) for all 2*blocks conv layers;
+// only the packed weights stream in (from L2) and the final activations go back to HBM.
+template <int C, int NTT>
+__global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_f32(Geo g, int S, int nblocks, const int32_t *n_dev,
+                                                               const float *__restrict__ in, const float *__restrict__ wpk,
+                                                               const float *__restrict__ bias, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int STRIDE = C + 8;    // dwords per LDS row
+    constexpr int S4 = STRIDE / 4;
+    const int n = *n_dev;
+    const int s0 = blockIdx.x * S;
+    if (s0 >= n) return;
+    const int HW = g.HW, W = g.W, H = g.H;
+    const int ns = min(S, n - s0);
+    const int R = ns * HW;           // valid rows in this workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int zrow = S * HW;         // shared zero row (same index in both images)
+    f32x4 *X4 = reinterpret_cast<f32x4 *>(lds);
+    f32x4 *Y4 = X4 + (zrow + 1) * S4;
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)s0 * HW * C);
+        const int nv = R * (C / 4);
+        for (int i = tid; i < nv; i += CONV_THREADS) {
+            int r = i / (C / 4), c4 = i - r * (C / 4);
+            X4[r * S4 + c4] = src[i];
+        }
+        if (tid < S4) {
+            X4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            Y4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    const int jrow = lane & 15, gq = lane >> 4;
+    // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
+    int vm[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; t++) {
+        int row = t * 16 + jrow;
+        int pos = row % HW, y = pos / W, x = pos - y * W;
+        int m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
+        }
+        vm[t] = row < R ? m : 0;
+    }
+    const int rowbase = jrow * S4 + gq;
+    const int zbase = zrow * S4 + gq;
+    const size_t wl = (size_t)C * C * 9;
+    for (int b = 0; b < nblocks; b++) {
+        conv_lds_f32<C, NTT>(X4, Y4, wpk + (size_t)(2 * b) * wl, bias + (2 * b) * C, vm, rowbase, zbase, W, R, wave, lane, 0);
+        __syncthreads();
+        conv_lds_f32<C, NTT>(Y4, X4, wpk + (size_t)(2 * b + 1) * wl, bias + (2 * b + 1) * C, vm, rowbase, zbase, W, R, wave, lane, 1);
+        __syncthreads();
+    }
+    {
+        f32x4 *dstg = reinterpret_cast<f32x4 *>(out + (size_t)s0 * HW * C);
+        const int nv = R * (C / 4);
+        for (int i = tid; i < nv; i += CONV_THREADS) {
+            int r = i / (C / 4), c4 = i - r * (C / 4);
+            dstg[i] = X4[r * S4 + c4];
         }
     }
 }
@@ -351,7 +368,6 @@ static void nn_free_device(NNState *nn)
 {
     for (void *p : nn->allocs) (void)hipFree(p);
     nn->allocs.clear();
-    nn->tower.clear();
     nn->ready = false;
 }
 
@@ -414,7 +430,8 @@ static bool bn_affine(NNState *nn, const std::string &p, int n, std::vector<doub
 }
 
 // conv3x3 [C][C][3][3] + following BN -> packed fragment order [C/16][9][C/16][64][4]
-static bool pack_conv(NNState *nn, const std::string &conv, const std::string &bn, int C, ConvLayer &L, std::string &err)
+static bool pack_conv(NNState *nn, const std::string &conv, const std::string &bn, int C, std::vector<float> &pk_all,
+                      std::vector<float> &bias_all, std::string &err)
 {
     const int Cr = nn->Craw;
     auto w = sd_get(nn, conv + ".weight", (size_t)Cr * Cr * 9, err); if (!w) return false;
@@ -434,42 +451,38 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
                         pk[((((size_t)ct * 9 + tap) * KC + kc) * 64 + lane) * 4 + e] = (float)v;
                     }
     for (int co = 0; co < Cr; co++) bias[co] = (float)((double)(*b)[co] * s[co] + t[co]);
-    L.w = nn_upload(nn, pk);
-    L.bias = nn_upload(nn, bias);
-    if (!L.w || !L.bias) { err = "hipMalloc failed (conv weights)"; return false; }
+    pk_all.insert(pk_all.end(), pk.begin(), pk.end());
+    bias_all.insert(bias_all.end(), bias.begin(), bias.end());
     return true;
 }
 
 // launches (or, with attr_only, raises the dynamic-LDS limit of) the instantiation for (C, NTT)
 template <int C, int NTT>
-static hipError_t conv_inst(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, const ConvLayer &L,
-                            const float *res, float *out, int flags, bool attr_only)
+static hipError_t tower_inst(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, float *out, bool attr_only)
 {
     if (attr_only)
-        return hipFuncSetAttribute((const void *)k_conv3x3<C, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
+        return hipFuncSetAttribute((const void *)k_tower_f32<C, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
     const int grid = (max_n + nn->S - 1) / nn->S;
-    hipLaunchKernelGGL((k_conv3x3<C, NTT>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, n_dev, in, L.w, L.bias,
-                       res, L.post_s, L.post_t, out, flags);
+    hipLaunchKernelGGL((k_tower_f32<C, NTT>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->blocks, n_dev, in,
+                       nn->tw, nn->tb, out);
     return hipSuccess;
 }
 template <int C>
-static hipError_t conv_inst_c(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, const ConvLayer &L,
-                              const float *res, float *out, int flags, bool attr_only)
+static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, float *out, bool attr_only)
 {
     switch (nn->NTT) {
-    case 4: return conv_inst<C, 4>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
-    case 8: return conv_inst<C, 8>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
-    default: return conv_inst<C, 13>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
+    case 4: return tower_inst<C, 4>(nn, s, n_dev, max_n, in, out, attr_only);
+    case 8: return tower_inst<C, 8>(nn, s, n_dev, max_n, in, out, attr_only);
+    default: return tower_inst<C, 13>(nn, s, n_dev, max_n, in, out, attr_only);
     }
 }
-static hipError_t conv_dispatch(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, const ConvLayer &L,
-                                const float *res, float *out, int flags, bool attr_only)
+static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, float *out, bool attr_only)
 {
     switch (nn->C) {
-    case 16: return conv_inst_c<16>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
-    case 32: return conv_inst_c<32>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
-    case 64: return conv_inst_c<64>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
-    default: return conv_inst_c<128>(nn, s, n_dev, max_n, in, L, res, out, flags, attr_only);
+    case 16: return tower_inst_c<16>(nn, s, n_dev, max_n, in, out, attr_only);
+    case 32: return tower_inst_c<32>(nn, s, n_dev, max_n, in, out, attr_only);
+    case 64: return tower_inst_c<64>(nn, s, n_dev, max_n, in, out, attr_only);
+    default: return tower_inst_c<128>(nn, s, n_dev, max_n, in, out, attr_only);
     }
 }
 
@@ -481,7 +494,6 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     const int C = nn->C, Cr = nn->Craw, hc = nn->hc, vf = nn->vf, HW = g.HW, A = g.A, K = hc * HW;
     for (void *p : nn->allocs) (void)hipFree(p);
     nn->allocs.clear();
-    nn->tower.clear();
     nn->ready = false;
     // bn_input
     {
@@ -507,13 +519,16 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         nn->w0 = nn_upload(nn, pk);
         nn->b0 = nn_upload(nn, bias);
     }
-    for (int i = 0; i < nn->blocks; i++) {
-        std::string p = "resnet.resblocks." + std::to_string(i);
-        ConvLayer a, b;
-        if (!pack_conv(nn, p + ".conv1", p + ".bn1", C, a, err)) return DBAZ_EINVAL;
-        if (!pack_conv(nn, p + ".conv2", p + ".bn2", C, b, err)) return DBAZ_EINVAL;
-        nn->tower.push_back(a);
-        nn->tower.push_back(b);
+    {
+        std::vector<float> pk_all, bias_all;
+        for (int i = 0; i < nn->blocks; i++) {
+            std::string p = "resnet.resblocks." + std::to_string(i);
+            if (!pack_conv(nn, p + ".conv1", p + ".bn1", C, pk_all, bias_all, err)) return DBAZ_EINVAL;
+            if (!pack_conv(nn, p + ".conv2", p + ".bn2", C, pk_all, bias_all, err)) return DBAZ_EINVAL;
+        }
+        nn->tw = nn_upload(nn, pk_all);
+        nn->tb = nn_upload(nn, bias_all);
+        if (!nn->tw || !nn->tb) { err = "hipMalloc failed (tower weights)"; return DBAZ_EDEVICE; }
     }
     // heads: conv1x1 + BN folded, rows [policy hc | value hc]
     {
@@ -552,31 +567,24 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     const size_t act = (size_t)nn->max_batch * HW * C;
     nn->actA = nn_alloc<float>(nn, act);
     nn->actB = nn_alloc<float>(nn, act);
-    nn->actC = nn_alloc<float>(nn, act);
     nn->hact = nn_alloc<float>(nn, (size_t)nn->max_batch * 2 * K);
-    if (!nn->actA || !nn->actB || !nn->actC || !nn->hact || !nn->wv1 || !nn->w0) { err = "hipMalloc failed (network buffers)"; return DBAZ_EDEVICE; }
+    if (!nn->actA || !nn->actB || !nn->hact || !nn->wv1 || !nn->w0) { err = "hipMalloc failed (network buffers)"; return DBAZ_EDEVICE; }
     // conv workgroup geometry: S whole samples, NT position tiles of 16 rows (<= MAXT)
-    const size_t lds_budget = 150 * 1024;
+    const size_t lds_budget = 158 * 1024; // of 160 KiB: two ping-pong activation images
     int S = (16 * MAXT) / HW;
     if (S < 1) S = 1;
-    while (S > 1 && (size_t)(S * HW + 1) * (C + 8) * 4 > lds_budget) S--;
+    while (S > 1 && 2 * (size_t)(S * HW + 1) * (C + 8) * 4 > lds_budget) S--;
     nn->S = S;
     nn->NT = (S * HW + 15) / 16;
-    if (nn->NT > MAXT) { err = "board too large for the conv tile"; return DBAZ_EINVAL; }
-    nn->conv_lds = (size_t)(S * HW + 1) * (C + 8) * 4;
+    nn->conv_lds = 2 * (size_t)(S * HW + 1) * (C + 8) * 4;
+    if (nn->NT > MAXT || nn->conv_lds > lds_budget) { err = "board/channels too large for the LDS-resident tower"; return DBAZ_EINVAL; }
     nn->NTT = nn->NT > 8 ? 13 : (nn->NT > 4 ? 8 : 4);
-    hipError_t he = conv_dispatch(nn, nullptr, nullptr, 0, nullptr, ConvLayer(), nullptr, nullptr, 0, true);
+    hipError_t he = tower_dispatch(nn, nullptr, nullptr, 0, nullptr, nullptr, true);
     if (he != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); return DBAZ_EDEVICE; }
     size_t hl = ((size_t)2 * hc * (C + 1) + (size_t)HW * (C + 1)) * 4;
     if (hl > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_head_conv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl);
     nn->ready = true;
     return DBAZ_OK;
-}
-
-static void launch_conv(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, const ConvLayer &L,
-                        const float *res, float *out, int flags)
-{
-    (void)conv_dispatch(nn, s, n_dev, max_n, in, L, res, out, flags, false);
 }
 
 void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *list_dev, const int32_t *n_dev, int max_n,
@@ -588,12 +596,8 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     size_t l0 = ((size_t)3 * (g.H + 2) * (g.W + 2) + (size_t)27 * C) * 4;
     hipLaunchKernelGGL(k_conv0, dim3(max_n), dim3(256), l0, s, g, C, feat, list_dev, n_dev, nn->in_s, nn->in_t, nn->w0, nn->b0, nn->actA);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    float *x = nn->actA, *y = nn->actB, *z = nn->actC;
-    for (int b = 0; b < nn->blocks; b++) {
-        launch_conv(nn, s, n_dev, max_n, x, nn->tower[2 * b], nullptr, y, 2);      // relu(bn1(conv1(x)))
-        launch_conv(nn, s, n_dev, max_n, y, nn->tower[2 * b + 1], x, z, 1 | 2);    // relu(bn2(conv2(y)) + x)
-        float *t = x; x = z; z = t;
-    }
+    float *x = nn->actB;
+    (void)tower_dispatch(nn, s, n_dev, max_n, nn->actA, x, false);
     if (ev_end) (void)hipEventRecord(ev_end, s);
     size_t hl = ((size_t)2 * hc * (C + 1) + (size_t)HW * (C + 1)) * 4;
     hipLaunchKernelGGL(k_head_conv, dim3(max_n), dim3(256), hl, s, g, C, hc, n_dev, x, nn->hw, nn->hb, nn->hact);
@@ -612,4 +616,4 @@ double nn_flops_per_sample(const NNState *nn)
     return f;
 }
 
-const char *nn_tower_kernel_name(const NNState *nn) { (void)nn; return "k_conv3x3"; }
+const char *nn_tower_kernel_name(const NNState *nn) { (void)nn; return "k_tower_f32"; }
