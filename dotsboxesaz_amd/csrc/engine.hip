@@ -410,6 +410,8 @@ extern "C" int dbaz_nn_predict(dbaz_engine *e, int32_t n, const float *X, float 
         for (int i = 0; i < m; i++)
             memcpy(p + (size_t)(off + i) * g.A, hp.data() + (size_t)i * g.AS, (size_t)g.A * 4);
     }
+    if (nn_overflowed(e->nn))
+        return set_error(e, DBAZ_EDEVICE, "nn_precision=1: an activation left the f16 range; use nn_precision=0 for this network");
     return DBAZ_OK;
 }
 
@@ -816,6 +818,8 @@ extern "C" int dbaz_get_counters(dbaz_engine *e, dbaz_counters *out)
     out->ms_nn_tower = e->ms_nn_tower;
     out->ms_tree = e->ms_total - e->ms_nn_tower;
     out->nn_launches = e->nn_launches;
+    if (nn_overflowed(e->nn))
+        return set_error(e, DBAZ_EDEVICE, "nn_precision=1: an activation left the f16 range; use nn_precision=0 for this network");
     return DBAZ_OK;
 }
 

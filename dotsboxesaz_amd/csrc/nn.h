@@ -20,3 +20,5 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
                 int max_n, float *P, float *V, int AS, hipEvent_t ev_begin, hipEvent_t ev_end);
 double nn_flops_per_sample(const NNState *nn);
 const char *nn_tower_kernel_name(const NNState *nn);
+// f16x3 mode: non-zero once an activation exceeded f16's range (results invalid: use precision 0)
+int nn_overflowed(NNState *nn);

@@ -44,12 +44,15 @@ struct NNState {
     int kind = 0, C = 0 /* padded to 16/32/64/128 */, Craw = 0 /* state_dict channels */, blocks = 0, hc = 0, vf = 0;
     bool ready = false;
     std::map<std::string, std::vector<float>> sd;
+    std::vector<float> osc_host;
     // device
     std::vector<void *> allocs;
     float *actA = nullptr, *actB = nullptr;
     float *in_s = nullptr, *in_t = nullptr;     // bn_input affine [3]
     float *w0 = nullptr, *b0 = nullptr;         // conv0 [9][3][C], [C]
     float *tw = nullptr, *tb = nullptr;         // tower: packed weights [2*blocks][C*C*9], bias [2*blocks][C]
+    float *tosc = nullptr;                      // f16x3: per-layer output scale 2^-(sw+ACT_SHIFT)
+    int *overflow = nullptr;                    // f16x3: set when an activation left f16's range
     float *hw = nullptr, *hb = nullptr;         // head conv1x1: [2*hc][C], [2*hc]
     float *hact = nullptr;                      // [batch][2][hc*HW]
     float *wp = nullptr, *bp = nullptr;         // policy FC transposed [hc*HW][A], [A]
@@ -247,6 +250,213 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_f32(Geo g, int S, int
 }
 
 // ------------------------------------------------------------------------------------
+// f16x3 variant of the same tower (nn_precision = 1): f32-grade results on the f16 MFMA pipe.
+// Every f32 operand is carried as an error-compensated pair of halves  v = hi + lo
+// (hi = rn_f16(v), lo = rn_f16(v - hi)); a product is evaluated as hi*hi + hi*lo + lo*hi with
+// f32 accumulation (v_mfma_f32_16x16x32_f16, three instructions per K=32 step); the dropped
+// lo*lo term is 2^-22 relative.  Weights are pre-scaled by a per-layer power of two (and
+// activations by 2^ACT_SHIFT) so that the lo halves stay in f16's normal range; the scales are
+// removed exactly in the epilogue.  Same LDS image size as the f32 tower: a row holds
+// [C halves hi | C halves lo | 32 B pad] = (C+8) dwords.
+// ------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define ACT_SHIFT 5
+#define ACT_SCALE 32.0f
+#define F16_GUARD 60000.0f
+
+union u128h { f32x4 f; f16x8 h; };
+
+template <int C, int NTT>
+__device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
+                                            const float *__restrict__ bias, float oscale, const int (&vm)[NTT], int rowbase,
+                                            int zbase, int W, int R, int wave, int lane, int residual, int *overflow)
+{
+    constexpr int S4 = (C + 8) / 4;  // 16-byte units per LDS row
+    constexpr int KS = C / 32;       // K=32 steps per tap
+    constexpr int LO = C / 8;        // unit offset of the lo halves inside a row
+    const int jrow = lane & 15, gq = lane >> 4;
+    bool ovf = false;
+    for (int ct = wave; ct < C / 16; ct += CONV_THREADS / 64) {
+        f32x4 acc[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // packed [ct][tap][ks][hi|lo][lane] 16-byte fragments
+        const f32x4 *wbase = wpk + (size_t)ct * 9 * KS * 2 * 64 + lane;
+        int addr[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; t++) addr[t] = (vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase - t * 16 * S4;
+        u128h ah_cur, al_cur, ah_nxt, al_nxt;
+        u128h bh_cur[NTT], bl_cur[NTT];
+        ah_cur.f = wbase[0];
+        al_cur.f = wbase[64];
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            bh_cur[t].f = src4[addr[t] + t * 16 * S4];
+            bl_cur[t].f = src4[addr[t] + t * 16 * S4 + LO];
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                u128h bh_nxt[NTT], bl_nxt[NTT];
+                if (ks == KS - 1) {
+                    const int tn = tap + 1;
+                    const int off = ((tn / 3 - 1) * W + (tn % 3 - 1)) * S4;
+#pragma unroll
+                    for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> tn) & 1) ? rowbase + off : zbase - t * 16 * S4;
+                    const size_t wi = (size_t)(tn < 9 ? tn * KS : 0) * 2 * 64;
+                    ah_nxt.f = wbase[wi];
+                    al_nxt.f = wbase[wi + 64];
+#pragma unroll
+                    for (int t = 0; t < NTT; t++) {
+                        bh_nxt[t].f = src4[addr[t] + t * 16 * S4];
+                        bl_nxt[t].f = src4[addr[t] + t * 16 * S4 + LO];
+                    }
+                } else {
+                    const size_t wi = (size_t)(tap * KS + ks + 1) * 2 * 64;
+                    ah_nxt.f = wbase[wi];
+                    al_nxt.f = wbase[wi + 64];
+#pragma unroll
+                    for (int t = 0; t < NTT; t++) {
+                        bh_nxt[t].f = src4[addr[t] + t * 16 * S4 + (ks + 1) * 4];
+                        bl_nxt[t].f = src4[addr[t] + t * 16 * S4 + (ks + 1) * 4 + LO];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah_cur.h, bh_cur[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah_cur.h, bl_cur[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al_cur.h, bh_cur[t].h, acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ah_cur = ah_nxt;
+                al_cur = al_nxt;
+#pragma unroll
+                for (int t = 0; t < NTT; t++) { bh_cur[t] = bh_nxt[t]; bl_cur[t] = bl_nxt[t]; }
+            }
+        }
+        // ---- epilogue: scale back, bias, residual, ReLU, split into halves
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + ct * 16 + gq * 4);
+        _Float16 *dsth = reinterpret_cast<_Float16 *>(dst4);
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            const int row = t * 16 + jrow;
+            if (row < R) {
+                _Float16 *ph = dsth + (size_t)row * (S4 * 8) + ct * 16 + gq * 4;
+                _Float16 *pl = ph + C;
+                f32x4 v = acc[t] * oscale + bv; // activation-scaled: value * 2^ACT_SHIFT
+                if (residual) {
+                    const f16x4 rh = *reinterpret_cast<const f16x4 *>(ph);
+                    const f16x4 rl = *reinterpret_cast<const f16x4 *>(pl);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] += (float)rh[k] + (float)rl[k];
+                }
+                f16x4 oh, ol;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float x = fmaxf(v[k], 0.f);
+                    ovf |= x > F16_GUARD;
+                    _Float16 h = (_Float16)x;
+                    oh[k] = h;
+                    ol[k] = (_Float16)(x - (float)h);
+                }
+                *reinterpret_cast<f16x4 *>(ph) = oh;
+                *reinterpret_cast<f16x4 *>(pl) = ol;
+            }
+        }
+    }
+    if (ovf) atomicOr(overflow, 1);
+}
+
+template <int C, int NTT>
+__global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_h3(Geo g, int S, int nblocks, const int32_t *n_dev,
+                                                              const float *__restrict__ in, const f32x4 *__restrict__ wpk,
+                                                              const float *__restrict__ bias, const float *__restrict__ oscale,
+                                                              float *__restrict__ out, int *overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int S4 = (C + 8) / 4;
+    const int n = *n_dev;
+    const int s0 = blockIdx.x * S;
+    if (s0 >= n) return;
+    const int HW = g.HW, W = g.W, H = g.H;
+    const int ns = min(S, n - s0);
+    const int R = ns * HW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int zrow = S * HW;
+    f32x4 *X4 = reinterpret_cast<f32x4 *>(lds);
+    f32x4 *Y4 = X4 + (zrow + 1) * S4;
+    {
+        // f32 NHWC input -> scaled (hi, lo) halves
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)s0 * HW * C);
+        _Float16 *xh = reinterpret_cast<_Float16 *>(X4);
+        const int nv = R * (C / 4);
+        bool ovf = false;
+        for (int i = tid; i < nv; i += CONV_THREADS) {
+            int r = i / (C / 4), c4 = i - r * (C / 4);
+            f32x4 v = src[i] * ACT_SCALE;
+            f16x4 oh, ol;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ovf |= fabsf(v[k]) > F16_GUARD;
+                _Float16 h = (_Float16)v[k];
+                oh[k] = h;
+                ol[k] = (_Float16)(v[k] - (float)h);
+            }
+            *reinterpret_cast<f16x4 *>(xh + (size_t)r * (S4 * 8) + c4 * 4) = oh;
+            *reinterpret_cast<f16x4 *>(xh + (size_t)r * (S4 * 8) + C + c4 * 4) = ol;
+        }
+        if (ovf) atomicOr(overflow, 1);
+        if (tid < S4) {
+            X4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            Y4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    const int jrow = lane & 15, gq = lane >> 4;
+    int vm[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; t++) {
+        int row = t * 16 + jrow;
+        int pos = row % HW, y = pos / W, x = pos - y * W;
+        int m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
+        }
+        vm[t] = row < R ? m : 0;
+    }
+    const int rowbase = jrow * S4 + gq;
+    const int zbase = zrow * S4 + gq;
+    const size_t wl = (size_t)C * C * 9 * 2 * 2 / 16; // 16-byte units per layer (hi + lo halves)
+    for (int b = 0; b < nblocks; b++) {
+        conv_lds_h3<C, NTT>(X4, Y4, wpk + (size_t)(2 * b) * wl, bias + (2 * b) * C, oscale[2 * b], vm, rowbase, zbase, W, R, wave,
+                            lane, 0, overflow);
+        __syncthreads();
+        conv_lds_h3<C, NTT>(Y4, X4, wpk + (size_t)(2 * b + 1) * wl, bias + (2 * b + 1) * C, oscale[2 * b + 1], vm, rowbase, zbase,
+                            W, R, wave, lane, 1, overflow);
+        __syncthreads();
+    }
+    {
+        f32x4 *dstg = reinterpret_cast<f32x4 *>(out + (size_t)s0 * HW * C);
+        const _Float16 *xh = reinterpret_cast<const _Float16 *>(X4);
+        const int nv = R * (C / 4);
+        for (int i = tid; i < nv; i += CONV_THREADS) {
+            int r = i / (C / 4), c4 = i - r * (C / 4);
+            const f16x4 h = *reinterpret_cast<const f16x4 *>(xh + (size_t)r * (S4 * 8) + c4 * 4);
+            const f16x4 l = *reinterpret_cast<const f16x4 *>(xh + (size_t)r * (S4 * 8) + C + c4 * 4);
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = ((float)h[k] + (float)l[k]) * (1.0f / ACT_SCALE);
+            dstg[i] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // heads
 // ------------------------------------------------------------------------------------
 // conv1x1 (C -> hc) + folded BN + ReLU for both heads; output in the reference's
@@ -390,6 +600,7 @@ int nn_configure(NNState *nn, int kind, int channels, int blocks, int head_chann
     nn->sd.clear();
     // the MFMA tile wants 16 | C: narrower nets run zero-padded (padded channels stay exactly 0)
     int cp = channels <= 16 ? 16 : channels <= 32 ? 32 : channels <= 64 ? 64 : 128;
+    if (nn->precision == 1 && cp < 32) cp = 32; // K = 32 per f16 MFMA step
     nn->kind = kind; nn->C = cp; nn->Craw = channels; nn->blocks = blocks; nn->hc = head_channels; nn->vf = value_fc;
     return DBAZ_OK;
 }
@@ -451,6 +662,41 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
                         pk[((((size_t)ct * 9 + tap) * KC + kc) * 64 + lane) * 4 + e] = (float)v;
                     }
     for (int co = 0; co < Cr; co++) bias[co] = (float)((double)(*b)[co] * s[co] + t[co]);
+    if (nn->precision == 1) {
+        // f16x3: folded weights scaled by 2^sw so that max|w| lands in [2^13, 2^14), split into
+        // (hi, lo) halves, packed [ct][tap][ks][hi|lo][lane][8]; bias carries the activation scale
+        double mx = 0;
+        for (int co = 0; co < Cr; co++)
+            for (int ci = 0; ci < Cr; ci++)
+                for (int tap = 0; tap < 9; tap++) mx = std::max(mx, fabs((double)(*w)[((size_t)co * Cr + ci) * 9 + tap] * s[co]));
+        int sw = 0;
+        if (mx > 0) { int e; frexp(mx, &e); sw = 14 - e; }
+        if (sw > 24) sw = 24;
+        if (sw < -24) sw = -24;
+        const double wscale = ldexp(1.0, sw);
+        const int KS = C / 32;
+        std::vector<_Float16> hp((size_t)C * C * 9 * 2, (_Float16)0.0f);
+        for (int ct = 0; ct < C / 16; ct++)
+            for (int tap = 0; tap < 9; tap++)
+                for (int ks = 0; ks < KS; ks++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int e = 0; e < 8; e++) {
+                            int co = ct * 16 + (lane & 15), ci = ks * 32 + 8 * (lane >> 4) + e;
+                            if (co >= Cr || ci >= Cr) continue;
+                            float v = (float)((double)(*w)[((size_t)co * Cr + ci) * 9 + tap] * s[co] * wscale);
+                            _Float16 h = (_Float16)v;
+                            _Float16 l = (_Float16)(v - (float)h);
+                            size_t base = ((((size_t)ct * 9 + tap) * KS + ks) * 2) * 64 * 8;
+                            hp[base + (size_t)lane * 8 + e] = h;
+                            hp[base + 64 * 8 + (size_t)lane * 8 + e] = l;
+                        }
+        const float *as_f = reinterpret_cast<const float *>(hp.data());
+        pk_all.insert(pk_all.end(), as_f, as_f + hp.size() / 2);
+        for (int co = 0; co < C; co++) bias[co] *= ACT_SCALE;
+        bias_all.insert(bias_all.end(), bias.begin(), bias.end());
+        nn->osc_host.push_back((float)ldexp(1.0, -sw)); // acc = 2^(sw+ACT_SHIFT) * sum ; keep 2^ACT_SHIFT
+        return true;
+    }
     pk_all.insert(pk_all.end(), pk.begin(), pk.end());
     bias_all.insert(bias_all.end(), bias.begin(), bias.end());
     return true;
@@ -460,9 +706,18 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
 template <int C, int NTT>
 static hipError_t tower_inst(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, float *out, bool attr_only)
 {
+    const int grid = (max_n + nn->S - 1) / nn->S;
+    if constexpr (C >= 32) {
+        if (nn->precision == 1) {
+            if (attr_only)
+                return hipFuncSetAttribute((const void *)k_tower_h3<C, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
+            hipLaunchKernelGGL((k_tower_h3<C, NTT>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->blocks, n_dev, in,
+                               reinterpret_cast<const f32x4 *>(nn->tw), nn->tb, nn->tosc, out, nn->overflow);
+            return hipSuccess;
+        }
+    }
     if (attr_only)
         return hipFuncSetAttribute((const void *)k_tower_f32<C, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
-    const int grid = (max_n + nn->S - 1) / nn->S;
     hipLaunchKernelGGL((k_tower_f32<C, NTT>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->blocks, n_dev, in,
                        nn->tw, nn->tb, out);
     return hipSuccess;
@@ -521,6 +776,7 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     }
     {
         std::vector<float> pk_all, bias_all;
+        nn->osc_host.clear();
         for (int i = 0; i < nn->blocks; i++) {
             std::string p = "resnet.resblocks." + std::to_string(i);
             if (!pack_conv(nn, p + ".conv1", p + ".bn1", C, pk_all, bias_all, err)) return DBAZ_EINVAL;
@@ -528,7 +784,11 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         }
         nn->tw = nn_upload(nn, pk_all);
         nn->tb = nn_upload(nn, bias_all);
-        if (!nn->tw || !nn->tb) { err = "hipMalloc failed (tower weights)"; return DBAZ_EDEVICE; }
+        if (nn->osc_host.empty()) nn->osc_host.push_back(1.0f);
+        nn->tosc = nn_upload(nn, nn->osc_host);
+        nn->overflow = nn_alloc<int>(nn, 4);
+        if (!nn->tw || !nn->tb || !nn->tosc || !nn->overflow) { err = "hipMalloc failed (tower weights)"; return DBAZ_EDEVICE; }
+        (void)hipMemset(nn->overflow, 0, 16);
     }
     // heads: conv1x1 + BN folded, rows [policy hc | value hc]
     {
@@ -616,4 +876,12 @@ double nn_flops_per_sample(const NNState *nn)
     return f;
 }
 
-const char *nn_tower_kernel_name(const NNState *nn) { (void)nn; return "k_tower_f32"; }
+const char *nn_tower_kernel_name(const NNState *nn) { return nn->precision == 1 ? "k_tower_h3" : "k_tower_f32"; }
+
+int nn_overflowed(NNState *nn)
+{
+    if (!nn || !nn->overflow) return 0;
+    int v = 0;
+    (void)hipMemcpy(&v, nn->overflow, 4, hipMemcpyDeviceToHost);
+    return v;
+}

@@ -97,3 +97,42 @@ def test_predict_before_commit_is_an_error():
     with pytest.raises(_lib.DbazError):
         e.load_state_dict({"bn_input.weight": np.ones(3, np.float32)}, "resnet", 16, 1, 4, 8)  # incomplete
     e.close()
+
+
+@pytest.mark.parametrize("rows,cols,ch,nb,n", [(6, 6, 64, 20, 64), (3, 3, 64, 20, 40), (9, 9, 64, 20, 10), (6, 6, 64, 3, 5),
+                                               (4, 2, 32, 2, 50), (6, 6, 128, 2, 19), (2, 3, 8, 1, 12)])
+def test_f16x3_split_precision_mode(rows, cols, ch, nb, n):
+    """nn_precision=1: every f32 operand is an error-compensated (hi, lo) pair of halves on the
+    f16 MFMA pipe with f32 accumulation.  Same 1e-4 north-star tolerance; the observed error is
+    of the order of f32 rounding noise (asserted < 2e-5)."""
+    torch.manual_seed(rows * 31 + cols + ch + n)
+    m = nn_ref.ResNetZeroRef(rows, cols, ch, nb)
+    nn_ref.randomize_bn(m, 5)
+    e = engine_for(rows, cols, m, n_slots=128, precision=1)
+    e0 = engine_for(rows, cols, m, n_slots=128, precision=0)
+    rng = np.random.RandomState(n)
+    X = rng.randint(0, 2, size=(n, 3, rows + 1, cols + 1)).astype(np.float32)
+    X[:, 2] = rng.randint(-2, rows * cols + 1, size=(n, 1, 1))
+    p, v = e.predict(X)
+    p0, v0 = e0.predict(X)
+    pr, vr = nn_ref.predict_sync(m, X)
+    err = max(np.abs(p - pr).max(), np.abs(v - vr).max())
+    err0 = max(np.abs(p0 - pr).max(), np.abs(v0 - vr).max())
+    print("f16x3 max abs err %.3g (exact-f32 MFMA path: %.3g)" % (err, err0))
+    assert err < 2e-5, err
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5)
+    e.close()
+    e0.close()
+
+
+def test_f16x3_reports_range_overflow():
+    """Activations beyond f16's range must not silently produce garbage."""
+    from dotsboxesaz_amd import _lib
+    torch.manual_seed(0)
+    m = nn_ref.ResNetZeroRef(3, 3, 32, 2)
+    with torch.no_grad():
+        m.resnet.conv0.weight.mul_(1e5)
+    e = engine_for(3, 3, m, n_slots=8, precision=1)
+    with pytest.raises(_lib.DbazError):
+        e.predict(np.ones((2, 3, 4, 4), np.float32))
+    e.close()
