@@ -275,67 +275,67 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
     constexpr int S4 = (C + 8) / 4;  // 16-byte units per LDS row
     constexpr int KS = C / 32;       // K=32 steps per tap
     constexpr int LO = C / 8;        // unit offset of the lo halves inside a row
+    constexpr int N = 9 * KS;        // pipeline steps per cout tile
     const int jrow = lane & 15, gq = lane >> 4;
     bool ovf = false;
     for (int ct = wave; ct < C / 16; ct += CONV_THREADS / 64) {
         f32x4 acc[NTT];
 #pragma unroll
         for (int t = 0; t < NTT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // packed [ct][tap][ks][hi|lo][lane] 16-byte fragments
-        const f32x4 *wbase = wpk + (size_t)ct * 9 * KS * 2 * 64 + lane;
+        // packed [ct][step = tap*KS + ks][hi|lo][lane] 16-byte fragments
+        const f32x4 *wbase = wpk + (size_t)ct * N * 2 * 64 + lane;
+        // Schedule of one step (all fragments SINGLE-buffered, reloaded right after their last use,
+        // so that at most NTT LDS reads are in flight at any wait -- lgkmcnt is a 4-bit counter):
+        //   G1 hi*hi, G3 lo*hi   -> bh is dead -> issue the NTT reads of the next step's bh
+        //   G2 hi*lo             -> bl is dead -> issue the NTT reads of the next step's bl
+        // Weight fragments (L2 -> registers) run two steps ahead in a 3-deep ring.
+        u128h a_h[3], a_l[3];
+        u128h bh[NTT], bl[NTT];
         int addr[NTT];
 #pragma unroll
         for (int t = 0; t < NTT; t++) addr[t] = (vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase - t * 16 * S4;
-        u128h ah_cur, al_cur, ah_nxt, al_nxt;
-        u128h bh_cur[NTT], bl_cur[NTT];
-        ah_cur.f = wbase[0];
-        al_cur.f = wbase[64];
-#pragma unroll
-        for (int t = 0; t < NTT; t++) {
-            bh_cur[t].f = src4[addr[t] + t * 16 * S4];
-            bl_cur[t].f = src4[addr[t] + t * 16 * S4 + LO];
+        a_h[0].f = wbase[0];
+        a_l[0].f = wbase[64];
+        if (N > 1) {
+            a_h[1].f = wbase[128];
+            a_l[1].f = wbase[192];
         }
-#pragma unroll 1
-        for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                u128h bh_nxt[NTT], bl_nxt[NTT];
-                if (ks == KS - 1) {
-                    const int tn = tap + 1;
-                    const int off = ((tn / 3 - 1) * W + (tn % 3 - 1)) * S4;
+        for (int t = 0; t < NTT; t++) bh[t].f = src4[addr[t] + t * 16 * S4];
 #pragma unroll
-                    for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> tn) & 1) ? rowbase + off : zbase - t * 16 * S4;
-                    const size_t wi = (size_t)(tn < 9 ? tn * KS : 0) * 2 * 64;
-                    ah_nxt.f = wbase[wi];
-                    al_nxt.f = wbase[wi + 64];
+        for (int t = 0; t < NTT; t++) bl[t].f = src4[addr[t] + t * 16 * S4 + LO];
 #pragma unroll
-                    for (int t = 0; t < NTT; t++) {
-                        bh_nxt[t].f = src4[addr[t] + t * 16 * S4];
-                        bl_nxt[t].f = src4[addr[t] + t * 16 * S4 + LO];
-                    }
-                } else {
-                    const size_t wi = (size_t)(tap * KS + ks + 1) * 2 * 64;
-                    ah_nxt.f = wbase[wi];
-                    al_nxt.f = wbase[wi + 64];
-#pragma unroll
-                    for (int t = 0; t < NTT; t++) {
-                        bh_nxt[t].f = src4[addr[t] + t * 16 * S4 + (ks + 1) * 4];
-                        bl_nxt[t].f = src4[addr[t] + t * 16 * S4 + (ks + 1) * 4 + LO];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah_cur.h, bh_cur[t].h, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah_cur.h, bl_cur[t].h, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al_cur.h, bh_cur[t].h, acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                ah_cur = ah_nxt;
-                al_cur = al_nxt;
-#pragma unroll
-                for (int t = 0; t < NTT; t++) { bh_cur[t] = bh_nxt[t]; bl_cur[t] = bl_nxt[t]; }
+        for (int i = 0; i < N; i++) {
+            const int cur = i % 3, pre = (i + 2) % 3;
+            if (i + 2 < N) {
+                a_h[pre].f = wbase[(size_t)(i + 2) * 128];
+                a_l[pre].f = wbase[(size_t)(i + 2) * 128 + 64];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[cur].h, bh[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[cur].h, bh[t].h, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
+            if (ni < N) {
+                if (nks == 0) {
+                    const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
+#pragma unroll
+                    for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> ntap) & 1) ? rowbase + off : zbase - t * 16 * S4;
+                }
+#pragma unroll
+                for (int t = 0; t < NTT; t++) bh[t].f = src4[addr[t] + t * 16 * S4 + nks * 4];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[cur].h, bl[t].h, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ni < N) {
+#pragma unroll
+                for (int t = 0; t < NTT; t++) bl[t].f = src4[addr[t] + t * 16 * S4 + nks * 4 + LO];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue: scale back, bias, residual, ReLU, split into halves
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + ct * 16 + gq * 4);
