@@ -47,7 +47,6 @@ struct NNState {
     std::vector<float> osc_host;
     // device
     std::vector<void *> allocs;
-    float *actA = nullptr, *actB = nullptr;
     float *in_s = nullptr, *in_t = nullptr;     // bn_input affine [3]
     float *w0 = nullptr, *b0 = nullptr;         // conv0 [9][3][C], [C]
     float *tw = nullptr, *tb = nullptr;         // tower: packed weights [2*blocks][C*C*9], bias [2*blocks][C]
@@ -61,43 +60,6 @@ struct NNState {
     int S = 1, NT = 1, NTT = 13;                // samples / position tiles per conv workgroup (NTT: compiled tile count)
     size_t conv_lds = 0;
 };
-
-// ------------------------------------------------------------------------------------
-// conv0: 3 -> C, VALU (K = 27), bn_input fused on load, BN0 folded, ReLU
-// ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_conv0(Geo g, int C, const float *__restrict__ feat, const int32_t *list,
-                                               const int32_t *n_dev, const float *in_s, const float *in_t,
-                                               const float *__restrict__ w /*[9][3][C]*/, const float *__restrict__ b,
-                                               float *__restrict__ out)
-{
-    extern __shared__ float lds0[];
-    const int j = blockIdx.x;
-    if (j >= *n_dev) return;
-    const int src = list ? list[j] : j;
-    const int H = g.H, W = g.W, HW = g.HW, PW = W + 2, PH = H + 2;
-    float *pad = lds0;                 // [3][PH][PW]
-    float *wl = lds0 + 3 * PH * PW;    // [27][C]
-    for (int i = threadIdx.x; i < 3 * PH * PW; i += blockDim.x) pad[i] = 0.0f;
-    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) wl[i] = w[i];
-    __syncthreads();
-    const float *f = feat + (size_t)src * 3 * HW;
-    for (int i = threadIdx.x; i < 3 * HW; i += blockDim.x) {
-        int c = i / HW, p = i - c * HW, y = p / W, x = p - y * W;
-        pad[(c * PH + y + 1) * PW + x + 1] = f[i] * in_s[c] + in_t[c];
-    }
-    __syncthreads();
-    float *o = out + (size_t)j * HW * C;
-    for (int i = threadIdx.x; i < HW * C; i += blockDim.x) {
-        int p = i / C, co = i - p * C, y = p / W, x = p - y * W;
-        float acc = b[co];
-        for (int tap = 0; tap < 9; tap++) {
-            int dy = tap / 3, dx = tap - dy * 3;
-            for (int c = 0; c < 3; c++)
-                acc += pad[(c * PH + y + dy) * PW + x + dx] * wl[(tap * 3 + c) * C + co];
-        }
-        o[i] = fmaxf(acc, 0.0f);
-    }
-}
 
 // ------------------------------------------------------------------------------------
 // conv3x3 C -> C on MFMA (f32 exact)
@@ -177,74 +139,6 @@ __device__ __forceinline__ void conv_lds_f32(const f32x4 *__restrict__ src4, f32
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                 dst4[o4] = v;
             }
-        }
-    }
-}
-
-// The whole residual tower in ONE launch: the S samples of a workgroup stay in LDS (two
-// ping-pong activation images of (S*HW+1) rows x (C+8) dwords) for all 2*blocks conv layers;
-// only the packed weights stream in (from L2) and the final activations go back to HBM.
-template <int C, int NTT>
-__global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_f32(Geo g, int S, int nblocks, const int32_t *n_dev,
-                                                               const float *__restrict__ in, const float *__restrict__ wpk,
-                                                               const float *__restrict__ bias, float *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int STRIDE = C + 8;    // dwords per LDS row
-    constexpr int S4 = STRIDE / 4;
-    const int n = *n_dev;
-    const int s0 = blockIdx.x * S;
-    if (s0 >= n) return;
-    const int HW = g.HW, W = g.W, H = g.H;
-    const int ns = min(S, n - s0);
-    const int R = ns * HW;           // valid rows in this workgroup
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int zrow = S * HW;         // shared zero row (same index in both images)
-    f32x4 *X4 = reinterpret_cast<f32x4 *>(lds);
-    f32x4 *Y4 = X4 + (zrow + 1) * S4;
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)s0 * HW * C);
-        const int nv = R * (C / 4);
-        for (int i = tid; i < nv; i += CONV_THREADS) {
-            int r = i / (C / 4), c4 = i - r * (C / 4);
-            X4[r * S4 + c4] = src[i];
-        }
-        if (tid < S4) {
-            X4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            Y4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    __syncthreads();
-    const int jrow = lane & 15, gq = lane >> 4;
-    // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
-    int vm[NTT];
-#pragma unroll
-    for (int t = 0; t < NTT; t++) {
-        int row = t * 16 + jrow;
-        int pos = row % HW, y = pos / W, x = pos - y * W;
-        int m = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
-        }
-        vm[t] = row < R ? m : 0;
-    }
-    const int rowbase = jrow * S4 + gq;
-    const int zbase = zrow * S4 + gq;
-    const size_t wl = (size_t)C * C * 9;
-    for (int b = 0; b < nblocks; b++) {
-        conv_lds_f32<C, NTT>(X4, Y4, wpk + (size_t)(2 * b) * wl, bias + (2 * b) * C, vm, rowbase, zbase, W, R, wave, lane, 0);
-        __syncthreads();
-        conv_lds_f32<C, NTT>(Y4, X4, wpk + (size_t)(2 * b + 1) * wl, bias + (2 * b + 1) * C, vm, rowbase, zbase, W, R, wave, lane, 1);
-        __syncthreads();
-    }
-    {
-        f32x4 *dstg = reinterpret_cast<f32x4 *>(out + (size_t)s0 * HW * C);
-        const int nv = R * (C / 4);
-        for (int i = tid; i < nv; i += CONV_THREADS) {
-            int r = i / (C / 4), c4 = i - r * (C / 4);
-            dstg[i] = X4[r * S4 + c4];
         }
     }
 }
@@ -370,45 +264,116 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
     if (ovf) atomicOr(overflow, 1);
 }
 
-template <int C, int NTT>
-__global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_h3(Geo g, int S, int nblocks, const int32_t *n_dev,
-                                                              const float *__restrict__ in, const f32x4 *__restrict__ wpk,
-                                                              const float *__restrict__ bias, const float *__restrict__ oscale,
-                                                              float *__restrict__ out, int *overflow)
+// ------------------------------------------------------------------------------------
+// The whole convolutional trunk in ONE launch per step.  A workgroup owns S samples; their
+// activations live in two ping-pong LDS images of (S*HW+1) rows x (C+8) dwords for
+//   conv0 (3 -> C, VALU, bn_input fused on load, BN0 folded, ReLU)
+//   2*blocks conv3x3 layers on MFMA (conv_lds_f32 or conv_lds_h3)
+//   the two 1x1 head convs (C -> 2*hc, VALU, BN folded, ReLU)
+// Only the leaf feature planes (588 B/sample) come in and the head activations
+// (2*hc*HW floats/sample, in the reference's x.view(n,-1) flatten order) go out; weights stream
+// from L2.  PREC 0: exact f32 (rows hold C floats); PREC 1: f16x3 (rows hold C hi + C lo halves
+// of the activation scaled by 2^ACT_SHIFT).
+// ------------------------------------------------------------------------------------
+template <int C, int PREC>
+__device__ __forceinline__ void act_store(float *lds, int row, int c, float v, bool &ovf)
+{
+    constexpr int STRIDE = C + 8;
+    if constexpr (PREC == 0) {
+        lds[row * STRIDE + c] = v;
+    } else {
+        _Float16 *h = reinterpret_cast<_Float16 *>(lds) + (size_t)row * (STRIDE * 2);
+        const float x = v * ACT_SCALE;
+        ovf |= fabsf(x) > F16_GUARD;
+        const _Float16 hi = (_Float16)x;
+        h[c] = hi;
+        h[C + c] = (_Float16)(x - (float)hi);
+    }
+}
+template <int C, int PREC>
+__device__ __forceinline__ float act_load(const float *lds, int row, int c)
+{
+    constexpr int STRIDE = C + 8;
+    if constexpr (PREC == 0) {
+        return lds[row * STRIDE + c];
+    } else {
+        const _Float16 *h = reinterpret_cast<const _Float16 *>(lds) + (size_t)row * (STRIDE * 2);
+        return ((float)h[c] + (float)h[C + c]) * (1.0f / ACT_SCALE);
+    }
+}
+
+struct TowerArgs {
+    const float *feat;       // [slot][3][HW] leaf feature planes
+    const int32_t *list;     // compacted slot list (nullptr: identity)
+    const int32_t *n_dev;    // number of samples
+    const float *in_s, *in_t; // bn_input affine
+    const float *w0, *b0;    // conv0 [27][C], [C]
+    const float *tw;         // tower weights, packed per layer
+    const float *tb;         // [2*blocks][C]
+    const float *tosc;       // f16x3 per-layer output scale
+    const float *hw, *hb;    // head conv1x1 [2*hc][C], [2*hc]
+    float *hact;             // out: [sample][2*hc*HW]
+    int *overflow;
+    int S, nblocks, hc;
+};
+
+template <int C, int NTT, int PREC>
+__global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int S4 = (C + 8) / 4;
-    const int n = *n_dev;
+    constexpr int STRIDE = C + 8;
+    constexpr int S4 = STRIDE / 4;
+    const int n = *a.n_dev;
+    const int S = a.S;
     const int s0 = blockIdx.x * S;
     if (s0 >= n) return;
     const int HW = g.HW, W = g.W, H = g.H;
     const int ns = min(S, n - s0);
-    const int R = ns * HW;
+    const int R = ns * HW;           // valid rows in this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int zrow = S * HW;
-    f32x4 *X4 = reinterpret_cast<f32x4 *>(lds);
-    f32x4 *Y4 = X4 + (zrow + 1) * S4;
+    const int zrow = S * HW;         // shared zero row (same index in both images)
+    float *X = lds;
+    float *Y = lds + (zrow + 1) * STRIDE;
+    f32x4 *X4 = reinterpret_cast<f32x4 *>(X);
+    f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
+    bool ovf = false;
+    // ---- conv0: stage zero-padded bn_input(planes) and the 27*C weights in the (idle) Y image
     {
-        // f32 NHWC input -> scaled (hi, lo) halves
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t)s0 * HW * C);
-        _Float16 *xh = reinterpret_cast<_Float16 *>(X4);
-        const int nv = R * (C / 4);
-        bool ovf = false;
-        for (int i = tid; i < nv; i += CONV_THREADS) {
-            int r = i / (C / 4), c4 = i - r * (C / 4);
-            f32x4 v = src[i] * ACT_SCALE;
-            f16x4 oh, ol;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                ovf |= fabsf(v[k]) > F16_GUARD;
-                _Float16 h = (_Float16)v[k];
-                oh[k] = h;
-                ol[k] = (_Float16)(v[k] - (float)h);
-            }
-            *reinterpret_cast<f16x4 *>(xh + (size_t)r * (S4 * 8) + c4 * 4) = oh;
-            *reinterpret_cast<f16x4 *>(xh + (size_t)r * (S4 * 8) + C + c4 * 4) = ol;
+        const int PW = W + 2, PH = H + 2, PP = 3 * PH * PW;
+        float *pad = Y;               // [ns][3][PH][PW]
+        float *wl = Y + S * PP;       // [27][C]
+        for (int i = tid; i < ns * PP; i += CONV_THREADS) pad[i] = 0.0f;
+        for (int i = tid; i < 27 * C; i += CONV_THREADS) wl[i] = a.w0[i];
+        __syncthreads();
+        for (int i = tid; i < ns * 3 * HW; i += CONV_THREADS) {
+            int sidx = i / (3 * HW), r = i - sidx * 3 * HW;
+            int c = r / HW, p = r - c * HW, y = p / W, x = p - y * W;
+            const int slot = a.list ? a.list[s0 + sidx] : s0 + sidx;
+            pad[sidx * PP + (c * PH + y + 1) * PW + x + 1] = a.feat[(size_t)slot * 3 * HW + r] * a.in_s[c] + a.in_t[c];
         }
-        if (ovf) atomicOr(overflow, 1);
+        __syncthreads();
+        // one work item = (row, 16 couts): its 27 inputs are read once, the weights are
+        // broadcast reads (16 lanes share an address)
+        for (int i = tid; i < R * (C / 16); i += CONV_THREADS) {
+            const int row = i % R, cq = i / R;
+            const int sidx = row / HW, p = row - sidx * HW, y = p / W, x = p - y * W;
+            const float *pp = pad + sidx * PP;
+            float in27[27];
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) in27[tap * 3 + c] = pp[(c * PH + y + tap / 3) * PW + x + tap % 3];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int co = cq * 16 + q * 4;
+                f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b0 + co);
+#pragma unroll
+                for (int k = 0; k < 27; k++) acc += in27[k] * *reinterpret_cast<const f32x4 *>(wl + k * C + co);
+#pragma unroll
+                for (int e = 0; e < 4; e++) act_store<C, PREC>(X, row, co + e, fmaxf(acc[e], 0.0f), ovf);
+            }
+        }
+        __syncthreads();
         if (tid < S4) {
             X4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
             Y4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -416,6 +381,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_h3(Geo g, int S, int 
     }
     __syncthreads();
     const int jrow = lane & 15, gq = lane >> 4;
+    // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
     int vm[NTT];
 #pragma unroll
     for (int t = 0; t < NTT; t++) {
@@ -431,65 +397,65 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_h3(Geo g, int S, int 
     }
     const int rowbase = jrow * S4 + gq;
     const int zbase = zrow * S4 + gq;
-    const size_t wl = (size_t)C * C * 9 * 2 * 2 / 16; // 16-byte units per layer (hi + lo halves)
-    for (int b = 0; b < nblocks; b++) {
-        conv_lds_h3<C, NTT>(X4, Y4, wpk + (size_t)(2 * b) * wl, bias + (2 * b) * C, oscale[2 * b], vm, rowbase, zbase, W, R, wave,
-                            lane, 0, overflow);
-        __syncthreads();
-        conv_lds_h3<C, NTT>(Y4, X4, wpk + (size_t)(2 * b + 1) * wl, bias + (2 * b + 1) * C, oscale[2 * b + 1], vm, rowbase, zbase,
-                            W, R, wave, lane, 1, overflow);
-        __syncthreads();
-    }
-    {
-        f32x4 *dstg = reinterpret_cast<f32x4 *>(out + (size_t)s0 * HW * C);
-        const _Float16 *xh = reinterpret_cast<const _Float16 *>(X4);
-        const int nv = R * (C / 4);
-        for (int i = tid; i < nv; i += CONV_THREADS) {
-            int r = i / (C / 4), c4 = i - r * (C / 4);
-            const f16x4 h = *reinterpret_cast<const f16x4 *>(xh + (size_t)r * (S4 * 8) + c4 * 4);
-            const f16x4 l = *reinterpret_cast<const f16x4 *>(xh + (size_t)r * (S4 * 8) + C + c4 * 4);
-            f32x4 v;
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = ((float)h[k] + (float)l[k]) * (1.0f / ACT_SCALE);
-            dstg[i] = v;
+    if constexpr (PREC == 0) {
+        const size_t wl = (size_t)C * C * 9;
+        for (int b = 0; b < a.nblocks; b++) {
+            conv_lds_f32<C, NTT>(X4, Y4, a.tw + (size_t)(2 * b) * wl, a.tb + (2 * b) * C, vm, rowbase, zbase, W, R, wave, lane, 0);
+            __syncthreads();
+            conv_lds_f32<C, NTT>(Y4, X4, a.tw + (size_t)(2 * b + 1) * wl, a.tb + (2 * b + 1) * C, vm, rowbase, zbase, W, R, wave, lane, 1);
+            __syncthreads();
+        }
+    } else {
+        const f32x4 *tw4 = reinterpret_cast<const f32x4 *>(a.tw);
+        const size_t wl = (size_t)C * C * 9 * 2 * 2 / 16; // 16-byte units per layer (hi + lo halves)
+        for (int b = 0; b < a.nblocks; b++) {
+            conv_lds_h3<C, NTT>(X4, Y4, tw4 + (size_t)(2 * b) * wl, a.tb + (2 * b) * C, a.tosc[2 * b], vm, rowbase, zbase, W, R, wave,
+                                lane, 0, a.overflow);
+            __syncthreads();
+            conv_lds_h3<C, NTT>(Y4, X4, tw4 + (size_t)(2 * b + 1) * wl, a.tb + (2 * b + 1) * C, a.tosc[2 * b + 1], vm, rowbase, zbase,
+                                W, R, wave, lane, 1, a.overflow);
+            __syncthreads();
         }
     }
+    // ---- head conv1x1 (both heads), results staged in Y as [sample][oc][pos] and written out coalesced
+    {
+        const int OC = 2 * a.hc;
+        float *wl = Y;                         // [OC][C+4]
+        float *stage = Y + OC * (C + 4);       // [ns][OC][HW]
+        for (int i = tid; i < OC * C; i += CONV_THREADS) {
+            int o = i / C, c = i - o * C;
+            wl[o * (C + 4) + c] = a.hw[i];
+        }
+        __syncthreads();
+        // one thread = one row: the row's C activations are read once into registers, the
+        // weights are wave-uniform (broadcast) float4 reads
+        if (tid < R) {
+            const int row = tid;
+            float xr[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) xr[c] = act_load<C, PREC>(X, row, c);
+            const int sidx = row / HW, p = row - sidx * HW;
+            for (int oc = 0; oc < OC; oc++) {
+                float acc = a.hb[oc];
+                const float *wr = wl + oc * (C + 4);
+#pragma unroll
+                for (int c = 0; c < C; c += 4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wr + c);
+                    acc += xr[c] * w4[0] + xr[c + 1] * w4[1] + xr[c + 2] * w4[2] + xr[c + 3] * w4[3];
+                }
+                stage[(sidx * OC + oc) * HW + p] = fmaxf(acc, 0.0f);
+            }
+        }
+        __syncthreads();
+        float *o = a.hact + (size_t)s0 * OC * HW;
+        for (int i = tid; i < ns * OC * HW; i += CONV_THREADS) o[i] = stage[i];
+    }
+    if (PREC == 1 && ovf) atomicOr(a.overflow, 1);
 }
 
 // ------------------------------------------------------------------------------------
 // heads
 // ------------------------------------------------------------------------------------
-// conv1x1 (C -> hc) + folded BN + ReLU for both heads; output in the reference's
-// flatten order x.view(n, -1) of [hc, H, W]:  hact[j][head][c*HW + pos]
-__global__ void __launch_bounds__(256) k_head_conv(Geo g, int C, int hc, const int32_t *n_dev, const float *__restrict__ act,
-                                                   const float *__restrict__ hw, const float *__restrict__ hb,
-                                                   float *__restrict__ hact)
-{
-    extern __shared__ float ldsh[];
-    const int j = blockIdx.x;
-    if (j >= *n_dev) return;
-    const int HW = g.HW;
-    float *wl = ldsh;                 // [2*hc][C+1]
-    float *al = ldsh + 2 * hc * (C + 1); // [HW][C+1]
-    for (int i = threadIdx.x; i < 2 * hc * C; i += blockDim.x) {
-        int o = i / C, c = i - o * C;
-        wl[o * (C + 1) + c] = hw[i];
-    }
-    const float *a = act + (size_t)j * HW * C;
-    for (int i = threadIdx.x; i < HW * C; i += blockDim.x) {
-        int p = i / C, c = i - p * C;
-        al[p * (C + 1) + c] = a[i];
-    }
-    __syncthreads();
-    float *o = hact + (size_t)j * 2 * hc * HW;
-    for (int i = threadIdx.x; i < 2 * hc * HW; i += blockDim.x) {
-        int oc = i / HW, p = i - oc * HW; // oc in [0, 2*hc): head = oc / hc
-        float acc = hb[oc];
-        for (int c = 0; c < C; c++) acc += al[p * (C + 1) + c] * wl[oc * (C + 1) + c];
-        o[i] = fmaxf(acc, 0.0f);
-    }
-}
-
 // policy FC + softmax, value FC0 + ReLU + FC1 + tanh; one block per sample
 __global__ void __launch_bounds__(256) k_head_fc(Geo g, int hc, int vf, int AS, const int32_t *list, const int32_t *n_dev,
                                                  const float *__restrict__ hact, const float *__restrict__ wp,
@@ -702,42 +668,40 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
     return true;
 }
 
-// launches (or, with attr_only, raises the dynamic-LDS limit of) the instantiation for (C, NTT)
+// launches (or, with attr_only, raises the dynamic-LDS limit of) the instantiation for (C, NTT, PREC)
 template <int C, int NTT>
-static hipError_t tower_inst(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, float *out, bool attr_only)
+static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
 {
     const int grid = (max_n + nn->S - 1) / nn->S;
     if constexpr (C >= 32) {
         if (nn->precision == 1) {
             if (attr_only)
-                return hipFuncSetAttribute((const void *)k_tower_h3<C, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
-            hipLaunchKernelGGL((k_tower_h3<C, NTT>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->blocks, n_dev, in,
-                               reinterpret_cast<const f32x4 *>(nn->tw), nn->tb, nn->tosc, out, nn->overflow);
+                return hipFuncSetAttribute((const void *)k_tower<C, NTT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
+            hipLaunchKernelGGL((k_tower<C, NTT, 1>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
             return hipSuccess;
         }
     }
     if (attr_only)
-        return hipFuncSetAttribute((const void *)k_tower_f32<C, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
-    hipLaunchKernelGGL((k_tower_f32<C, NTT>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, nn->S, nn->blocks, n_dev, in,
-                       nn->tw, nn->tb, out);
+        return hipFuncSetAttribute((const void *)k_tower<C, NTT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
+    hipLaunchKernelGGL((k_tower<C, NTT, 0>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
     return hipSuccess;
 }
 template <int C>
-static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, float *out, bool attr_only)
+static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
 {
     switch (nn->NTT) {
-    case 4: return tower_inst<C, 4>(nn, s, n_dev, max_n, in, out, attr_only);
-    case 8: return tower_inst<C, 8>(nn, s, n_dev, max_n, in, out, attr_only);
-    default: return tower_inst<C, 13>(nn, s, n_dev, max_n, in, out, attr_only);
+    case 4: return tower_inst<C, 4>(nn, s, ta, max_n, attr_only);
+    case 8: return tower_inst<C, 8>(nn, s, ta, max_n, attr_only);
+    default: return tower_inst<C, 13>(nn, s, ta, max_n, attr_only);
     }
 }
-static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const int32_t *n_dev, int max_n, const float *in, float *out, bool attr_only)
+static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
 {
     switch (nn->C) {
-    case 16: return tower_inst_c<16>(nn, s, n_dev, max_n, in, out, attr_only);
-    case 32: return tower_inst_c<32>(nn, s, n_dev, max_n, in, out, attr_only);
-    case 64: return tower_inst_c<64>(nn, s, n_dev, max_n, in, out, attr_only);
-    default: return tower_inst_c<128>(nn, s, n_dev, max_n, in, out, attr_only);
+    case 16: return tower_inst_c<16>(nn, s, ta, max_n, attr_only);
+    case 32: return tower_inst_c<32>(nn, s, ta, max_n, attr_only);
+    case 64: return tower_inst_c<64>(nn, s, ta, max_n, attr_only);
+    default: return tower_inst_c<128>(nn, s, ta, max_n, attr_only);
     }
 }
 
@@ -824,25 +788,27 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         nn->wv1 = nn_upload(nn, *w1);
         nn->bv1 = nn_upload(nn, *b1);
     }
-    const size_t act = (size_t)nn->max_batch * HW * C;
-    nn->actA = nn_alloc<float>(nn, act);
-    nn->actB = nn_alloc<float>(nn, act);
     nn->hact = nn_alloc<float>(nn, (size_t)nn->max_batch * 2 * K);
-    if (!nn->actA || !nn->actB || !nn->hact || !nn->wv1 || !nn->w0) { err = "hipMalloc failed (network buffers)"; return DBAZ_EDEVICE; }
+    if (!nn->hact || !nn->wv1 || !nn->w0) { err = "hipMalloc failed (network buffers)"; return DBAZ_EDEVICE; }
     // conv workgroup geometry: S whole samples, NT position tiles of 16 rows (<= MAXT)
     const size_t lds_budget = 158 * 1024; // of 160 KiB: two ping-pong activation images
+    // the idle image doubles as staging for conv0 (padded planes + 27*C weights) and the head convs
+    auto lds_bytes = [&](int S_) {
+        const size_t img = (size_t)(S_ * HW + 1) * (C + 8);
+        const size_t need0 = (size_t)S_ * 3 * (g.H + 2) * (g.W + 2) + (size_t)27 * C;
+        const size_t need1 = (size_t)2 * hc * (C + 4) + (size_t)S_ * 2 * hc * HW;
+        return (img + std::max(img, std::max(need0, need1))) * 4;
+    };
     int S = (16 * MAXT) / HW;
     if (S < 1) S = 1;
-    while (S > 1 && 2 * (size_t)(S * HW + 1) * (C + 8) * 4 > lds_budget) S--;
+    while (S > 1 && lds_bytes(S) > lds_budget) S--;
+    if (lds_bytes(S) > lds_budget) { err = "board / channels / head_channels too large for the LDS-resident tower"; return DBAZ_EINVAL; }
     nn->S = S;
     nn->NT = (S * HW + 15) / 16;
-    nn->conv_lds = 2 * (size_t)(S * HW + 1) * (C + 8) * 4;
-    if (nn->NT > MAXT || nn->conv_lds > lds_budget) { err = "board/channels too large for the LDS-resident tower"; return DBAZ_EINVAL; }
+    nn->conv_lds = lds_bytes(S);
     nn->NTT = nn->NT > 8 ? 13 : (nn->NT > 4 ? 8 : 4);
-    hipError_t he = tower_dispatch(nn, nullptr, nullptr, 0, nullptr, nullptr, true);
+    hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), 0, true);
     if (he != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); return DBAZ_EDEVICE; }
-    size_t hl = ((size_t)2 * hc * (C + 1) + (size_t)HW * (C + 1)) * 4;
-    if (hl > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_head_conv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl);
     nn->ready = true;
     return DBAZ_OK;
 }
@@ -851,16 +817,15 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
                 float *P, float *V, int AS, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     const Geo &g = nn->g;
-    const int C = nn->C, hc = nn->hc, HW = g.HW;
+    const int hc = nn->hc, HW = g.HW;
     if (max_n > nn->max_batch) max_n = nn->max_batch;
-    size_t l0 = ((size_t)3 * (g.H + 2) * (g.W + 2) + (size_t)27 * C) * 4;
-    hipLaunchKernelGGL(k_conv0, dim3(max_n), dim3(256), l0, s, g, C, feat, list_dev, n_dev, nn->in_s, nn->in_t, nn->w0, nn->b0, nn->actA);
+    TowerArgs ta;
+    ta.feat = feat; ta.list = list_dev; ta.n_dev = n_dev; ta.in_s = nn->in_s; ta.in_t = nn->in_t; ta.w0 = nn->w0; ta.b0 = nn->b0;
+    ta.tw = nn->tw; ta.tb = nn->tb; ta.tosc = nn->tosc; ta.hw = nn->hw; ta.hb = nn->hb; ta.hact = nn->hact;
+    ta.overflow = nn->overflow; ta.S = nn->S; ta.nblocks = nn->blocks; ta.hc = hc;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    float *x = nn->actB;
-    (void)tower_dispatch(nn, s, n_dev, max_n, nn->actA, x, false);
+    (void)tower_dispatch(nn, s, ta, max_n, false);
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    size_t hl = ((size_t)2 * hc * (C + 1) + (size_t)HW * (C + 1)) * 4;
-    hipLaunchKernelGGL(k_head_conv, dim3(max_n), dim3(256), hl, s, g, C, hc, n_dev, x, nn->hw, nn->hb, nn->hact);
     size_t fl = ((size_t)2 * hc * HW + 256 + 64) * 4;
     hipLaunchKernelGGL(k_head_fc, dim3(max_n), dim3(256), fl, s, g, hc, nn->vf, AS, list_dev, n_dev, nn->hact, nn->wp, nn->bp,
                        nn->wv0, nn->bv0, nn->wv1, nn->bv1, P, V);
@@ -876,7 +841,7 @@ double nn_flops_per_sample(const NNState *nn)
     return f;
 }
 
-const char *nn_tower_kernel_name(const NNState *nn) { return nn->precision == 1 ? "k_tower_h3" : "k_tower_f32"; }
+const char *nn_tower_kernel_name(const NNState *nn) { (void)nn; return "k_tower"; }
 
 int nn_overflowed(NNState *nn)
 {
