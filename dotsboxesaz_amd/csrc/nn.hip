@@ -54,8 +54,9 @@ struct NNState {
     int *overflow = nullptr;                    // f16x3: set when an activation left f16's range
     float *hw = nullptr, *hb = nullptr;         // head conv1x1: [2*hc][C], [2*hc]
     float *hact = nullptr;                      // [batch][2][hc*HW]
-    float *wp = nullptr, *bp = nullptr;         // policy FC transposed [hc*HW][A], [A]
-    float *wv0 = nullptr, *bv0 = nullptr;       // value FC0 transposed [hc*HW][vf], [vf]
+    float *wfc = nullptr, *bfc = nullptr;       // head FC GEMM: packed weights [ntp+ntv][KP/16][64][4], bias [(ntp+ntv)*16]
+    int KP = 0, RS4 = 0, ntp = 0, ntv = 0;
+    size_t fc_lds = 0;
     float *wv1 = nullptr, *bv1 = nullptr;       // [vf], [1]
     int S = 1, NT = 1, NTT = 13;                // samples / position tiles per conv workgroup (NTT: compiled tile count)
     size_t conv_lds = 0;
@@ -456,59 +457,91 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 // ------------------------------------------------------------------------------------
 // heads
 // ------------------------------------------------------------------------------------
-// policy FC + softmax, value FC0 + ReLU + FC1 + tanh; one block per sample
-__global__ void __launch_bounds__(256) k_head_fc(Geo g, int hc, int vf, int AS, const int32_t *list, const int32_t *n_dev,
-                                                 const float *__restrict__ hact, const float *__restrict__ wp,
-                                                 const float *__restrict__ bp, const float *__restrict__ wv0,
-                                                 const float *__restrict__ bv0, const float *__restrict__ wv1,
-                                                 const float *__restrict__ bv1, float *__restrict__ P, float *__restrict__ V)
+// Head FCs as one batched GEMM on f32 MFMA: a workgroup takes 16 samples;
+//   Out^T[out][sample] = Wfc[out][k] * hact^T[k][sample]
+// with A = FC weights pre-packed in fragment order ([job][k/16][lane][4], streamed from L2) and
+// B = the 16 samples' head activations staged in LDS (row stride = 2 mod 16 float4 units:
+// conflict-free ds_read_b128).  Jobs 0..ntp-1 are 16-output tiles of the policy FC, jobs
+// ntp.. of the value FC0.  Then softmax over the A logits (= exp(log_softmax), nn.py:159) and
+// tanh(FC1(relu(FC0))) per sample.
+struct HeadArgs {
+    const int32_t *list, *n_dev;
+    const float *hact;      // [sample][2][K]
+    const float *wfc;       // packed [ntp+ntv][KC][64][4]
+    const float *bfc;       // [(ntp+ntv)*16] bias per GEMM output (0 for padding)
+    const float *wv1, *bv1; // value FC1 [vf], [1]
+    float *P, *V;
+    int K, KP /*K padded to 16*/, RS4 /*LDS row stride, float4 units*/, ntp, ntv, vf, AS;
+};
+
+__global__ void __launch_bounds__(256) k_head_fc(Geo g, HeadArgs h)
 {
-    extern __shared__ float ldsf[];
-    const int j = blockIdx.x;
-    if (j >= *n_dev) return;
-    const int dst = list ? list[j] : j;
-    const int HW = g.HW, A = g.A, K = hc * HW;
-    float *hp = ldsf;          // [K]
-    float *hv = ldsf + K;      // [K]
-    float *red = ldsf + 2 * K; // [256 + vf]
-    const float *h = hact + (size_t)j * 2 * K;
-    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) ldsf[i] = h[i];
-    __syncthreads();
-    const int t = threadIdx.x;
-    float logit = -INFINITY;
-    if (t < A) {
-        float acc = bp[t];
-        for (int k = 0; k < K; k++) acc += hp[k] * wp[(size_t)k * A + t];
-        logit = acc;
-    }
-    // value hidden units on the threads after the policy ones
-    if (t >= 256 - vf) {
-        int u = t - (256 - vf);
-        float acc = bv0[u];
-        for (int k = 0; k < K; k++) acc += hv[k] * wv0[(size_t)k * vf + u];
-        red[256 + u] = fmaxf(acc, 0.0f);
-    }
-    red[t] = logit;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+    extern __shared__ __attribute__((aligned(16))) float ldsf[];
+    const int n = *h.n_dev;
+    const int j0 = blockIdx.x * 16;
+    if (j0 >= n) return;
+    const int ns = min(16, n - j0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int RS = h.RS4 * 4, KP = h.KP, K = h.K, A = g.A;
+    const int NJ = h.ntp + h.ntv, LGS = NJ * 16 + 1;
+    float *act = ldsf;               // [16][RS]: one head's activations at a time
+    float *lg = ldsf + 16 * RS;      // [16][LGS]
+    const int jrow = lane & 15, gq = lane >> 4;
+    const f32x4 *act4 = reinterpret_cast<const f32x4 *>(act);
+    const int KC = KP / 16;
+    for (int hd = 0; hd < 2; hd++) {
         __syncthreads();
-    }
-    const float mx = red[0];
-    __syncthreads();
-    const float ex = (t < A) ? expf(logit - mx) : 0.0f;
-    red[t] = ex;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (t < s) red[t] += red[t + s];
+        for (int i = tid; i < 16 * KP; i += 256) {
+            int sidx = i / KP, k = i - sidx * KP;
+            float v = 0.0f;
+            if (sidx < ns && k < K) v = h.hact[((size_t)(j0 + sidx) * 2 + hd) * K + k];
+            act[sidx * RS + k] = v;
+        }
         __syncthreads();
+        const int jb = hd == 0 ? 0 : h.ntp, je = hd == 0 ? h.ntp : NJ;
+        for (int job = jb + wave; job < je; job += 4) {
+            const f32x4 *wb = reinterpret_cast<const f32x4 *>(h.wfc) + (size_t)job * KC * 64 + lane;
+            const f32x4 *bb = act4 + jrow * h.RS4 + gq;
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            int kc = 0;
+            for (; kc + 1 < KC; kc += 2) {
+                const f32x4 a0 = wb[(size_t)kc * 64], a1 = wb[(size_t)(kc + 1) * 64];
+                const f32x4 b0 = bb[kc * 4], b1 = bb[(kc + 1) * 4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc1, 0, 0, 0);
+                }
+            }
+            if (kc < KC) {
+                const f32x4 a0 = wb[(size_t)kc * 64];
+                const f32x4 b0 = bb[kc * 4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc0, 0, 0, 0);
+            }
+            const f32x4 acc = acc0 + acc1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = job * 16 + gq * 4 + r;
+                lg[jrow * LGS + o] = acc[r] + h.bfc[o];
+            }
+        }
     }
-    const float sum = red[0];
-    if (t < A) P[(size_t)dst * AS + t] = ex / sum;
-    if (t == 0) {
-        float acc = bv1[0];
-        for (int u = 0; u < vf; u++) acc += red[256 + u] * wv1[u];
-        V[dst] = tanhf(acc);
+    __syncthreads();
+    for (int sidx = wave; sidx < ns; sidx += 4) {
+        const int dst = h.list ? h.list[j0 + sidx] : j0 + sidx;
+        const float *l = lg + sidx * LGS;
+        float mx = -INFINITY;
+        for (int o = lane; o < A; o += 64) mx = fmaxf(mx, l[o]);
+        for (int s = 32; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+        float sum = 0.0f;
+        for (int o = lane; o < A; o += 64) sum += expf(l[o] - mx);
+        for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
+        for (int o = lane; o < A; o += 64) h.P[(size_t)dst * h.AS + o] = expf(l[o] - mx) / sum;
+        float hv = 0.0f;
+        for (int u = lane; u < h.vf; u += 64) hv += fmaxf(l[h.ntp * 16 + u], 0.0f) * h.wv1[u];
+        for (int s = 32; s > 0; s >>= 1) hv += __shfl_xor(hv, s);
+        if (lane == 0) h.V[dst] = tanhf(hv + h.bv1[0]);
     }
 }
 
@@ -561,7 +594,6 @@ int nn_configure(NNState *nn, int kind, int channels, int blocks, int head_chann
     if (kind != DBAZ_EVAL_RESNET) { err = "only DBAZ_EVAL_RESNET is implemented in this build"; return DBAZ_EINVAL; }
     if (channels < 1 || channels > 128) { err = "channels must be in 1..128"; return DBAZ_EINVAL; }
     if (blocks < 0 || head_channels < 1 || value_fc < 1 || value_fc > 64) { err = "bad network shape"; return DBAZ_EINVAL; }
-    if (nn->g.A > 256 - value_fc) { err = "A + value_fc must be <= 256"; return DBAZ_EINVAL; }
     nn_free_device(nn);
     nn->sd.clear();
     // the MFMA tile wants 16 | C: narrower nets run zero-padded (padded channels stay exactly 0)
@@ -773,20 +805,41 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         nn->hb = nn_upload(nn, hb);
         auto wp = sd_get(nn, "policy_head.fc.weight", (size_t)A * K, err); if (!wp) return DBAZ_EINVAL;
         auto bp = sd_get(nn, "policy_head.fc.bias", A, err); if (!bp) return DBAZ_EINVAL;
-        std::vector<float> wpt((size_t)K * A);
-        for (int a = 0; a < A; a++) for (int k = 0; k < K; k++) wpt[(size_t)k * A + a] = (*wp)[(size_t)a * K + k];
-        nn->wp = nn_upload(nn, wpt);
-        nn->bp = nn_upload(nn, *bp);
         auto w0 = sd_get(nn, "value_head.fc0.weight", (size_t)vf * K, err); if (!w0) return DBAZ_EINVAL;
         auto b0 = sd_get(nn, "value_head.fc0.bias", vf, err); if (!b0) return DBAZ_EINVAL;
         auto w1 = sd_get(nn, "value_head.fc1.weight", vf, err); if (!w1) return DBAZ_EINVAL;
         auto b1 = sd_get(nn, "value_head.fc1.bias", 1, err); if (!b1) return DBAZ_EINVAL;
-        std::vector<float> w0t((size_t)K * vf);
-        for (int u = 0; u < vf; u++) for (int k = 0; k < K; k++) w0t[(size_t)k * vf + u] = (*w0)[(size_t)u * K + k];
-        nn->wv0 = nn_upload(nn, w0t);
-        nn->bv0 = nn_upload(nn, *b0);
+        const int KP = (K + 15) & ~15, KC = KP / 16;
+        const int ntp = (A + 15) / 16, ntv = (vf + 15) / 16, NJ = ntp + ntv;
+        std::vector<float> pk((size_t)NJ * KC * 64 * 4, 0.0f), bias((size_t)NJ * 16, 0.0f);
+        for (int job = 0; job < NJ; job++) {
+            const bool pol = job < ntp;
+            const int tile = pol ? job : job - ntp, nout = pol ? A : vf;
+            const std::vector<float> &wm = pol ? *wp : *w0;
+            for (int kc = 0; kc < KC; kc++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 4; e++) {
+                        int o = tile * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4) + e;
+                        if (o < nout && k < K) pk[(((size_t)job * KC + kc) * 64 + lane) * 4 + e] = wm[(size_t)o * K + k];
+                    }
+            for (int i = 0; i < 16; i++) {
+                int o = tile * 16 + i;
+                if (o < nout) bias[job * 16 + i] = pol ? (*bp)[o] : (*b0)[o];
+            }
+        }
+        nn->wfc = nn_upload(nn, pk);
+        nn->bfc = nn_upload(nn, bias);
         nn->wv1 = nn_upload(nn, *w1);
         nn->bv1 = nn_upload(nn, *b1);
+        nn->KP = KP; nn->ntp = ntp; nn->ntv = ntv;
+        int rs4 = KP / 4;
+        rs4 = ((rs4 + 15) / 16) * 16 + 2; // = 2 mod 16 float4 units
+        nn->RS4 = rs4;
+        nn->fc_lds = ((size_t)16 * rs4 * 4 + (size_t)16 * (NJ * 16 + 1)) * 4;
+        if (nn->fc_lds > 158 * 1024) { err = "head FC tile does not fit LDS"; return DBAZ_EINVAL; }
+        if (hipFuncSetAttribute((const void *)k_head_fc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->fc_lds) != hipSuccess) {
+            err = "hipFuncSetAttribute(k_head_fc) failed"; return DBAZ_EDEVICE;
+        }
     }
     nn->hact = nn_alloc<float>(nn, (size_t)nn->max_batch * 2 * K);
     if (!nn->hact || !nn->wv1 || !nn->w0) { err = "hipMalloc failed (network buffers)"; return DBAZ_EDEVICE; }
@@ -826,9 +879,10 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     (void)tower_dispatch(nn, s, ta, max_n, false);
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    size_t fl = ((size_t)2 * hc * HW + 256 + 64) * 4;
-    hipLaunchKernelGGL(k_head_fc, dim3(max_n), dim3(256), fl, s, g, hc, nn->vf, AS, list_dev, n_dev, nn->hact, nn->wp, nn->bp,
-                       nn->wv0, nn->bv0, nn->wv1, nn->bv1, P, V);
+    HeadArgs ha;
+    ha.list = list_dev; ha.n_dev = n_dev; ha.hact = nn->hact; ha.wfc = nn->wfc; ha.bfc = nn->bfc; ha.wv1 = nn->wv1; ha.bv1 = nn->bv1;
+    ha.P = P; ha.V = V; ha.K = hc * HW; ha.KP = nn->KP; ha.RS4 = nn->RS4; ha.ntp = nn->ntp; ha.ntv = nn->ntv; ha.vf = nn->vf; ha.AS = AS;
+    hipLaunchKernelGGL(k_head_fc, dim3((max_n + 15) / 16), dim3(256), nn->fc_lds, s, g, ha);
 }
 
 double nn_flops_per_sample(const NNState *nn)
