@@ -88,7 +88,7 @@ __device__ __forceinline__ void conv_lds_f32(const f32x4 *__restrict__ src4, f32
         const f32x4 *wbase = reinterpret_cast<const f32x4 *>(wpk) + (size_t)ct * 9 * KC * 64 + lane;
         int addr[NTT];
 #pragma unroll
-        for (int t = 0; t < NTT; t++) addr[t] = (vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase - t * 16 * S4;
+        for (int t = 0; t < NTT; t++) addr[t] = (vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4;
         f32x4 a_cur = wbase[0];
         f32x4 b_cur[NTT];
 #pragma unroll
@@ -103,7 +103,7 @@ __device__ __forceinline__ void conv_lds_f32(const f32x4 *__restrict__ src4, f32
                     const int tn = tap + 1;
                     const int off = ((tn / 3 - 1) * W + (tn % 3 - 1)) * S4;
 #pragma unroll
-                    for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> tn) & 1) ? rowbase + off : zbase - t * 16 * S4;
+                    for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> tn) & 1) ? rowbase + off : zbase + ((rowbase + off) & 15) - t * 16 * S4;
                     a_nxt = wbase[(size_t)(tn < 9 ? tn * KC : 0) * 64];
 #pragma unroll
                     for (int t = 0; t < NTT; t++) b_nxt[t] = src4[addr[t] + t * 16 * S4];
@@ -188,7 +188,7 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
         u128h bh[NTT], bl[NTT];
         int addr[NTT];
 #pragma unroll
-        for (int t = 0; t < NTT; t++) addr[t] = (vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase - t * 16 * S4;
+        for (int t = 0; t < NTT; t++) addr[t] = (vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4;
         a_h[0].f = wbase[0];
         a_l[0].f = wbase[64];
         if (N > 1) {
@@ -217,7 +217,7 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
                 if (nks == 0) {
                     const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
 #pragma unroll
-                    for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> ntap) & 1) ? rowbase + off : zbase - t * 16 * S4;
+                    for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> ntap) & 1) ? rowbase + off : zbase + ((rowbase + off) & 15) - t * 16 * S4;
                 }
 #pragma unroll
                 for (int t = 0; t < NTT; t++) bh[t].f = src4[addr[t] + t * 16 * S4 + nks * 4];
@@ -332,9 +332,14 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     const int ns = min(S, n - s0);
     const int R = ns * HW;           // valid rows in this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int zrow = S * HW;         // shared zero row (same index in both images)
+    // Zero REGION (3 rows, starting at a multiple of 16 float4 units) behind the S*HW rows of each
+    // image: a lane whose tap falls outside the board reads the zero whose bank slot equals the
+    // slot of its natural address, so out-of-image lanes never collide with in-image lanes of
+    // their ds_read_b128 group (one shared zero row cost +1 LDS cycle per group: 44 % of LDS time).
+    const int zu = (S * HW * S4 + 15) & ~15;  // unit index of the zero region
+    const int img_units = zu + 3 * S4;
     float *X = lds;
-    float *Y = lds + (zrow + 1) * STRIDE;
+    float *Y = lds + (size_t)img_units * 4;
     f32x4 *X4 = reinterpret_cast<f32x4 *>(X);
     f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
     bool ovf = false;
@@ -375,9 +380,9 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
             }
         }
         __syncthreads();
-        if (tid < S4) {
-            X4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            Y4[zrow * S4 + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tid < 3 * S4) {
+            X4[zu + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            Y4[zu + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
     __syncthreads();
@@ -397,7 +402,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         vm[t] = row < R ? m : 0;
     }
     const int rowbase = jrow * S4 + gq;
-    const int zbase = zrow * S4 + gq;
+    const int zbase = zu; // multiple of 16 units; the per-lane slot is added per tap
     if constexpr (PREC == 0) {
         const size_t wl = (size_t)C * C * 9;
         for (int b = 0; b < a.nblocks; b++) {
@@ -847,7 +852,8 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     const size_t lds_budget = 158 * 1024; // of 160 KiB: two ping-pong activation images
     // the idle image doubles as staging for conv0 (padded planes + 27*C weights) and the head convs
     auto lds_bytes = [&](int S_) {
-        const size_t img = (size_t)(S_ * HW + 1) * (C + 8);
+        const size_t s4 = (C + 8) / 4;
+        const size_t img = ((((size_t)S_ * HW * s4 + 15) & ~(size_t)15) + 3 * s4) * 4; // floats, incl. zero region
         const size_t need0 = (size_t)S_ * 3 * (g.H + 2) * (g.W + 2) + (size_t)27 * C;
         const size_t need1 = (size_t)2 * hc * (C + 4) + (size_t)S_ * 2 * hc * HW;
         return (img + std::max(img, std::max(need0, need1))) * 4;
