@@ -181,14 +181,18 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
         const f32x4 *wbase = wpk + (size_t)ct * N * 2 * 64 + lane;
         // Schedule of one step (all fragments SINGLE-buffered, reloaded right after their last use,
         // so that at most NTT LDS reads are in flight at any wait -- lgkmcnt is a 4-bit counter):
-        //   G1 hi*hi, G3 lo*hi   -> bh is dead -> issue the NTT reads of the next step's bh
-        //   G2 hi*lo             -> bl is dead -> issue the NTT reads of the next step's bl
+        //   G1 hi*hi
+        //   G3 lo*hi, each MFMA followed by the ds_read that reloads its (now dead) bh[t]
+        //   G2 hi*lo, each MFMA followed by the ds_read that reloads its bl[t]
+        // i.e. loads and address math issue in the MFMAs' shadow instead of as separate blocks.
         // Weight fragments (L2 -> registers) run two steps ahead in a 3-deep ring.
         u128h a_h[3], a_l[3];
         u128h bh[NTT], bl[NTT];
-        int addr[NTT];
+        const char *sb = reinterpret_cast<const char *>(src4);
+        int ab[NTT]; // BYTE address of this lane's fragment for the current tap (tile constant folded out)
 #pragma unroll
-        for (int t = 0; t < NTT; t++) addr[t] = (vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4;
+        for (int t = 0; t < NTT; t++)
+            ab[t] = ((vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4) * 16;
         a_h[0].f = wbase[0];
         a_l[0].f = wbase[64];
         if (N > 1) {
@@ -196,41 +200,42 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
             a_l[1].f = wbase[192];
         }
 #pragma unroll
-        for (int t = 0; t < NTT; t++) bh[t].f = src4[addr[t] + t * 16 * S4];
+        for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4);
 #pragma unroll
-        for (int t = 0; t < NTT; t++) bl[t].f = src4[addr[t] + t * 16 * S4 + LO];
+        for (int t = 0; t < NTT; t++) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + LO * 16);
 #pragma unroll
         for (int i = 0; i < N; i++) {
             const int cur = i % 3, pre = (i + 2) % 3;
+            const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
             if (i + 2 < N) {
                 a_h[pre].f = wbase[(size_t)(i + 2) * 128];
                 a_l[pre].f = wbase[(size_t)(i + 2) * 128 + 64];
             }
             __builtin_amdgcn_sched_barrier(0);
+            // G1: hi*hi (the next tap's addresses are computed in its shadow)
 #pragma unroll
             for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[cur].h, bh[t].h, acc[t], 0, 0, 0);
+            if (ni < N && nks == 0) {
+                const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
+                const int zt = zbase + ((rowbase + off) & 15);
 #pragma unroll
-            for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[cur].h, bh[t].h, acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
-            if (ni < N) {
-                if (nks == 0) {
-                    const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
-#pragma unroll
-                    for (int t = 0; t < NTT; t++) addr[t] = ((vm[t] >> ntap) & 1) ? rowbase + off : zbase + ((rowbase + off) & 15) - t * 16 * S4;
-                }
-#pragma unroll
-                for (int t = 0; t < NTT; t++) bh[t].f = src4[addr[t] + t * 16 * S4 + nks * 4];
+                for (int t = 0; t < NTT; t++) ab[t] = (((vm[t] >> ntap) & 1) ? rowbase + off : zt - t * 16 * S4) * 16;
             }
             __builtin_amdgcn_sched_barrier(0);
+            // G3: lo*hi; bh[t] is dead after its MFMA -> reload it for the next step right there
 #pragma unroll
-            for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[cur].h, bl[t].h, acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ni < N) {
-#pragma unroll
-                for (int t = 0; t < NTT; t++) bl[t].f = src4[addr[t] + t * 16 * S4 + nks * 4 + LO];
+            for (int t = 0; t < NTT; t++) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[cur].h, bh[t].h, acc[t], 0, 0, 0);
+                if (ni < N) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            // G2: hi*lo; same for bl[t]
+#pragma unroll
+            for (int t = 0; t < NTT; t++) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[cur].h, bl[t].h, acc[t], 0, 0, 0);
+                if (ni < N) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64 + LO * 16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // ---- epilogue: scale back, bias, residual, ReLU, split into halves
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + ct * 16 + gq * 4);
