@@ -29,7 +29,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define CONV_THREADS 256
+#define CONV_THREADS 512 // 8 waves: two per SIMD, wave = (cout tile, half of the position tiles)
 #define MAXT 13 // position tiles (16 rows each) per workgroup
 
 struct ConvLayer {
@@ -58,7 +58,7 @@ struct NNState {
     int KP = 0, RS4 = 0, ntp = 0, ntv = 0;
     size_t fc_lds = 0;
     float *wv1 = nullptr, *bv1 = nullptr;       // [vf], [1]
-    int S = 1, NT = 1, NTT = 13;                // samples / position tiles per conv workgroup (NTT: compiled tile count)
+    int S = 1, NT = 1, NTT = 7;                 // samples / position tiles per conv workgroup (NTT: compiled tile count)
     size_t conv_lds = 0;
 };
 
@@ -76,12 +76,12 @@ struct NNState {
 template <int C, int NTT>
 __device__ __forceinline__ void conv_lds_f32(const f32x4 *__restrict__ src4, f32x4 *dst4, const float *__restrict__ wpk,
                                              const float *__restrict__ bias, const int (&vm)[NTT], int rowbase, int zbase,
-                                             int W, int R, int wave, int lane, int residual)
+                                             int W, int R, int wave, int lane, int residual, int tbase)
 {
     constexpr int S4 = (C + 8) / 4;  // float4 per LDS row
     constexpr int KC = C / 16;       // 16-cin chunks per tap
     const int jrow = lane & 15, gq = lane >> 4;
-    for (int ct = wave; ct < C / 16; ct += CONV_THREADS / 64) {
+    for (int ct = wave & 3; ct < C / 16; ct += 4) {
         f32x4 acc[NTT];
 #pragma unroll
         for (int t = 0; t < NTT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -132,7 +132,7 @@ __device__ __forceinline__ void conv_lds_f32(const f32x4 *__restrict__ src4, f32
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + ct * 16 + gq * 4);
 #pragma unroll
         for (int t = 0; t < NTT; t++) {
-            const int row = t * 16 + jrow;
+            const int row = (tbase + t) * 16 + jrow;
             if (row < R) {
                 const int o4 = row * S4 + ct * 4 + gq;
                 f32x4 v = acc[t] + bv;
@@ -165,7 +165,7 @@ union u128h { f32x4 f; f16x8 h; };
 template <int C, int NTT>
 __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
                                             const float *__restrict__ bias, float oscale, const int (&vm)[NTT], int rowbase,
-                                            int zbase, int W, int R, int wave, int lane, int residual, int *overflow)
+                                            int zbase, int W, int R, int wave, int lane, int residual, int *overflow, int tbase)
 {
     constexpr int S4 = (C + 8) / 4;  // 16-byte units per LDS row
     constexpr int KS = C / 32;       // K=32 steps per tap
@@ -173,7 +173,7 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
     constexpr int N = 9 * KS;        // pipeline steps per cout tile
     const int jrow = lane & 15, gq = lane >> 4;
     bool ovf = false;
-    for (int ct = wave; ct < C / 16; ct += CONV_THREADS / 64) {
+    for (int ct = wave & 3; ct < C / 16; ct += 4) {
         f32x4 acc[NTT];
 #pragma unroll
         for (int t = 0; t < NTT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -242,7 +242,7 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
         _Float16 *dsth = reinterpret_cast<_Float16 *>(dst4);
 #pragma unroll
         for (int t = 0; t < NTT; t++) {
-            const int row = t * 16 + jrow;
+            const int row = (tbase + t) * 16 + jrow;
             if (row < R) {
                 _Float16 *ph = dsth + (size_t)row * (S4 * 8) + ct * 16 + gq * 4;
                 _Float16 *pl = ph + C;
@@ -393,10 +393,11 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     __syncthreads();
     const int jrow = lane & 15, gq = lane >> 4;
     // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
+    const int tbase = (wave >> 2) * NTT; // waves 4-7 take the second half of the position tiles
     int vm[NTT];
 #pragma unroll
     for (int t = 0; t < NTT; t++) {
-        int row = t * 16 + jrow;
+        int row = (tbase + t) * 16 + jrow;
         int pos = row % HW, y = pos / W, x = pos - y * W;
         int m = 0;
 #pragma unroll
@@ -406,14 +407,14 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         }
         vm[t] = row < R ? m : 0;
     }
-    const int rowbase = jrow * S4 + gq;
+    const int rowbase = (tbase * 16 + jrow) * S4 + gq;
     const int zbase = zu; // multiple of 16 units; the per-lane slot is added per tap
     if constexpr (PREC == 0) {
         const size_t wl = (size_t)C * C * 9;
         for (int b = 0; b < a.nblocks; b++) {
-            conv_lds_f32<C, NTT>(X4, Y4, a.tw + (size_t)(2 * b) * wl, a.tb + (2 * b) * C, vm, rowbase, zbase, W, R, wave, lane, 0);
+            conv_lds_f32<C, NTT>(X4, Y4, a.tw + (size_t)(2 * b) * wl, a.tb + (2 * b) * C, vm, rowbase, zbase, W, R, wave, lane, 0, tbase);
             __syncthreads();
-            conv_lds_f32<C, NTT>(Y4, X4, a.tw + (size_t)(2 * b + 1) * wl, a.tb + (2 * b + 1) * C, vm, rowbase, zbase, W, R, wave, lane, 1);
+            conv_lds_f32<C, NTT>(Y4, X4, a.tw + (size_t)(2 * b + 1) * wl, a.tb + (2 * b + 1) * C, vm, rowbase, zbase, W, R, wave, lane, 1, tbase);
             __syncthreads();
         }
     } else {
@@ -421,10 +422,10 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         const size_t wl = (size_t)C * C * 9 * 2 * 2 / 16; // 16-byte units per layer (hi + lo halves)
         for (int b = 0; b < a.nblocks; b++) {
             conv_lds_h3<C, NTT>(X4, Y4, tw4 + (size_t)(2 * b) * wl, a.tb + (2 * b) * C, a.tosc[2 * b], vm, rowbase, zbase, W, R, wave,
-                                lane, 0, a.overflow);
+                                lane, 0, a.overflow, tbase);
             __syncthreads();
             conv_lds_h3<C, NTT>(Y4, X4, tw4 + (size_t)(2 * b + 1) * wl, a.tb + (2 * b + 1) * C, a.tosc[2 * b + 1], vm, rowbase, zbase,
-                                W, R, wave, lane, 1, a.overflow);
+                                W, R, wave, lane, 1, a.overflow, tbase);
             __syncthreads();
         }
     }
@@ -732,9 +733,9 @@ template <int C>
 static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
 {
     switch (nn->NTT) {
+    case 2: return tower_inst<C, 2>(nn, s, ta, max_n, attr_only);
     case 4: return tower_inst<C, 4>(nn, s, ta, max_n, attr_only);
-    case 8: return tower_inst<C, 8>(nn, s, ta, max_n, attr_only);
-    default: return tower_inst<C, 13>(nn, s, ta, max_n, attr_only);
+    default: return tower_inst<C, 7>(nn, s, ta, max_n, attr_only);
     }
 }
 static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
@@ -870,7 +871,7 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     nn->S = S;
     nn->NT = (S * HW + 15) / 16;
     nn->conv_lds = lds_bytes(S);
-    nn->NTT = nn->NT > 8 ? 13 : (nn->NT > 4 ? 8 : 4);
+    nn->NTT = nn->NT > 8 ? 7 : (nn->NT > 4 ? 4 : 2); // tiles per wave; two waves cover 2*NTT >= NT tiles
     hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), 0, true);
     if (he != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); return DBAZ_EDEVICE; }
     nn->ready = true;
