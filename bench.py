@@ -73,37 +73,13 @@ def cpu_baseline(rows, cols, sims, budget_s, channels, blocks):
                        "%.0f s (%d expansions)" % (rows, cols, sims, blocks, channels, dt, total))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--board", type=int, default=6)
-    ap.add_argument("--slots", type=int, default=8192)
-    ap.add_argument("--sims", type=int, default=800)
-    ap.add_argument("--channels", type=int, default=64)
-    ap.add_argument("--blocks", type=int, default=20)
-    ap.add_argument("--evaluator", default="resnet", choices=["resnet", "formula", "uniform"])
-    ap.add_argument("--precision", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, torch):
+    """One timed region on this rank's GPU; returns the raw measurements."""
     from dotsboxesaz_amd.engine import Engine
     from dotsboxesaz_amd import nn as dnn
-
     rows = cols = args.board
     eng = Engine(rows, cols, args.slots, mcts_num_read=args.sims, noise=(0.8, 0.25), reuse_tree=True,
-                 evaluator=args.evaluator, seed=1000 + rank, device=local_rank, nn_precision=args.precision)
+                 evaluator=args.evaluator, seed=1000 + rank, device=local_rank, nn_precision=precision)
     if args.evaluator == "resnet":
         torch.manual_seed(0)
         model = dnn.ResNetZero(dnn.resnet_params(rows, cols, args.channels, args.blocks))
@@ -120,59 +96,112 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    eng.step(args.warmup)
+    eng.step(warmup)
     sync_all()
     c0 = eng.counters()
     eng.timing_begin()
     t0 = time.perf_counter()
-    eng.step(args.steps)
+    eng.step(steps)
     eng.timing_end()
     sync_all()
     dt = time.perf_counter() - t0
     c1 = eng.counters()
     if c1["error_slots"]:
         raise SystemExit("engine reported %d slots in error (node pool exhausted?)" % c1["error_slots"])
-    exp = c1["expansions"] - c0["expansions"]
-    evals = c1["nn_evals"] - c0["nn_evals"]
-    spath = c1["sum_path"] - c0["sum_path"]
-    term = c1["terminal_leaves"] - c0["terminal_leaves"]
-    tot = torch.tensor([float(exp), float(evals), dt], dtype=torch.float64)
+    m = {k: c1[k] - c0[k] for k in ("expansions", "nn_evals", "sum_path", "terminal_leaves", "moves_played")}
+    m.update(dt=dt, ms_total=c1["ms_total"], ms_nn_tower=c1["ms_nn_tower"], pool_high_water=c1["pool_high_water"],
+             nodes_per_slot=eng.cfg.nodes_per_slot or 6 * (args.sims + 2), E=eng.E)
     if dist is not None:
-        tdev = tot.cuda()
+        tdev = torch.tensor([float(m["expansions"]), float(m["nn_evals"]), dt], dtype=torch.float64).cuda()
         mx = tdev.clone()
         dist.all_reduce(tdev, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        exp_all, evals_all, dt_max = float(tdev[0]), float(tdev[1]), float(mx[2])
+        m.update(exp_all=float(tdev[0]), evals_all=float(tdev[1]), dt_max=float(mx[2]))
     else:
-        exp_all, evals_all, dt_max = float(exp), float(evals), dt
+        m.update(exp_all=float(m["expansions"]), evals_all=float(m["nn_evals"]), dt_max=dt)
+    return eng, m
 
+
+def tower_roofline(args, m, steps, precision):
+    HW = (args.board + 1) ** 2
+    conv_flops = 2.0 * HW * 9 * args.channels * args.channels  # per sample per conv3x3 layer
+    ach = m["nn_evals"] * conv_flops * 2 * args.blocks / (m["ms_nn_tower"] * 1e-3) / 1e12
+    peak = F32_MFMA_PEAK_TFLOPS if precision == 0 else F16_MFMA_PEAK_TFLOPS / 3.0
+    return {"bound": "mfma",
+            "kernel": "k_tower<%d,*,%d> (conv0 + 2*%d conv3x3 + head 1x1 convs fused, LDS-resident)" % (args.channels, precision, args.blocks),
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "peak_note": ("dense f32 MFMA" if precision == 0 else
+                          "dense f16 MFMA / 3 (three f16 MFMAs per f32-grade product); algorithmic flops counted once"),
+            "avg_launch_us": 1e3 * m["ms_nn_tower"] / steps,
+            "flops_per_launch": m["nn_evals"] / steps * conv_flops * 2 * args.blocks,
+            "tower_ms_per_step": m["ms_nn_tower"] / steps,
+            "tree_and_heads_ms_per_step": (m["ms_total"] - m["ms_nn_tower"]) / steps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--board", type=int, default=6)
+    ap.add_argument("--slots", type=int, default=8192)
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--blocks", type=int, default=20)
+    ap.add_argument("--evaluator", default="resnet", choices=["resnet", "formula", "uniform"])
+    ap.add_argument("--precision", type=int, default=1,
+                    help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-side-run", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    eng, m = run_engine(args, args.precision, args.steps, args.warmup, rank, local_rank, world, dist, torch)
     # replay all-gather at iteration end (multi-GPU): whatever finished + a fixed synthetic shard
     gather = None
     if dist is not None:
         from dotsboxesaz_amd.self_play import gather_replay
         rows_total, ms = gather_replay(eng, dist, synthetic_rows=args.slots * 8)
         gather = dict(rows=rows_total, ms=ms)
+    eng.close()
+    side = None
+    if args.evaluator == "resnet" and args.precision == 1 and not args.no_f32_side_run:
+        st = max(20, args.steps // 6)
+        eng0, m0 = run_engine(args, 0, st, max(5, args.warmup // 5), rank, local_rank, world, dist, torch)
+        eng0.close()
+        side = (m0, st)
 
     if rank == 0:
+        rows = cols = args.board
         HW = (rows + 1) * (cols + 1)
-        conv_flops = 2.0 * HW * 9 * args.channels * args.channels  # per sample per tower conv launch
-        launches = args.steps  # one fused-tower launch per step (all 2*blocks conv layers)
+        exp, spath, term = m["expansions"], m["sum_path"], m["terminal_leaves"]
         out = {
-            "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt_max, "unit": "expansions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
+            "metric": "mcts_node_expansions_per_sec", "value": m["exp_all"] / m["dt_max"], "unit": "expansions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * m["dt_max"] / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == 0 else "f32 (f16x3 split MFMA, f32 accumulate)",
+            "dtype": "f32" if args.precision == 0 or args.evaluator != "resnet" else
+                     "f32 via f16x3 (hi,lo)-split MFMA, f32 accumulate; max |dp|,|dv| vs torch fp32 = 1e-6 (tests/test_hip_nn.py)",
             "data": "synthetic",
             "config": {"workload": "%dx%d board, %d concurrent games/GPU, %d sims/move, evaluator=%s %dx%d "
                                    "random-init, noise (0.8,0.25), tree reuse, mid-game start population"
                                    % (rows, cols, args.slots, args.sims, args.evaluator, args.blocks, args.channels),
                        "baseline_config": "configs[2]" if (args.board, args.slots, args.sims) == (6, 8192, 800) else "custom",
                        "parallelism": "games sharded, %d rank(s)" % world},
-            "per_gpu": exp_all / dt_max / world,
-            "nn_evals_per_sec": evals_all / dt_max,
+            "per_gpu": m["exp_all"] / m["dt_max"] / world,
+            "nn_evals_per_sec": m["evals_all"] / m["dt_max"],
             "mean_path_len": spath / max(1, exp), "terminal_leaf_fraction": term / max(1, exp),
-            "pool_high_water": c1["pool_high_water"], "nodes_per_slot": eng.cfg.nodes_per_slot or 6 * (args.sims + 2),
-            "moves_played": c1["moves_played"] - c0["moves_played"],
+            "pool_high_water": m["pool_high_water"], "nodes_per_slot": m["nodes_per_slot"],
+            "moves_played": m["moves_played"],
         }
         # games/s: expansions/s divided by the measured mean expansions of a full game
         # (DESIGN.md "Measurement"; 6x6 @ 800 sims: 63.2k)
@@ -180,23 +209,29 @@ def main():
         if exp_per_game:
             out["games_per_sec_est"] = out["value"] / exp_per_game
             out["expansions_per_game_assumed"] = exp_per_game
-        if args.evaluator == "resnet" and c1["ms_nn_tower"] > 0:
-            ach = evals * conv_flops * 2 * args.blocks / (c1["ms_nn_tower"] * 1e-3) / 1e12
-            peak = F32_MFMA_PEAK_TFLOPS if args.precision == 0 else F16_MFMA_PEAK_TFLOPS / 3.0
-            out["roofline"] = {"bound": "mfma", "kernel": "k_tower_%s<%d> (2*%d conv3x3 layers fused, LDS-resident)" % ("f32" if args.precision == 0 else "f16x3", args.channels, args.blocks), "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                               "avg_launch_us": 1e3 * c1["ms_nn_tower"] / launches,
-                               "flops_per_launch": evals / args.steps * conv_flops * 2 * args.blocks,
-                               "tower_ms_per_step": c1["ms_nn_tower"] / args.steps,
-                               "tree_and_heads_ms_per_step": (c1["ms_total"] - c1["ms_nn_tower"]) / args.steps}
+        if args.evaluator == "resnet" and m["ms_nn_tower"] > 0:
+            out["roofline"] = tower_roofline(args, m, args.steps, args.precision)
+            pmc = os.path.join(REPO, "profiles", "r01_pmc_tower.json")
+            if os.path.exists(pmc) and args.precision == 1 and (args.board, args.slots) == (6, 8192):
+                t = json.load(open(pmc))
+                out["roofline"]["traffic"] = t.get("traffic_bytes_per_launch")
+                out["roofline"]["traffic_note"] = t.get("note")
+                out["roofline"]["mfma_busy_frac"] = t.get("mfma_busy_frac")
+            else:
+                out["roofline"]["traffic"] = None
         else:
             # tree kernels only: HBM roofline with SURVEY 8d's algorithmic bytes per simulation
             A = 2 * HW
             L = spath / max(1, exp)
             bps = (L - 1) * (12 * A + A / 4 + 12) + L * 16 + (12 * A + (A + 7) // 8 + 8) + 2 * (3 * HW * 4) + 4 * A + 4
-            ach = exp * bps / (c1["ms_total"] * 1e-3) / 1e9
+            ach = exp * bps / (m["ms_total"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_select+k_expand_backup", "achieved": ach, "peak": 8000.0,
                                "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "bytes_per_sim": bps}
+        if side:
+            m0, st = side
+            out["exact_f32_mode"] = {"value": m0["exp_all"] / m0["dt_max"], "unit": "expansions/s", "steps": st,
+                                     "ms_per_step": 1e3 * m0["dt_max"] / st, "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                                     "roofline": tower_roofline(args, m0, st, 0)}
         if gather:
             out["replay_allgather"] = gather
         if not args.no_cpu_baseline:
@@ -205,7 +240,6 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
 
 
 if __name__ == "__main__":

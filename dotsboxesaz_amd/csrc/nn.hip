@@ -75,7 +75,7 @@ struct NNState {
 // in place (every element is read and written by the same lane).
 template <int C, int NTT>
 __device__ __forceinline__ void conv_lds_f32(const f32x4 *__restrict__ src4, f32x4 *dst4, const float *__restrict__ wpk,
-                                             const float *__restrict__ bias, const int (&vm)[NTT], int rowbase, int zbase,
+                                             const float *__restrict__ bias, const int *vm, int rowbase, int zbase,
                                              int W, int R, int wave, int lane, int residual, int tbase)
 {
     constexpr int S4 = (C + 8) / 4;  // float4 per LDS row
@@ -164,7 +164,7 @@ union u128h { f32x4 f; f16x8 h; };
 
 template <int C, int NTT>
 __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
-                                            const float *__restrict__ bias, float oscale, const int (&vm)[NTT], int rowbase,
+                                            const float *__restrict__ bias, float oscale, const int *vm, int rowbase,
                                             int zbase, int W, int R, int wave, int lane, int residual, int *overflow, int tbase)
 {
     constexpr int S4 = (C + 8) / 4;  // 16-byte units per LDS row
@@ -323,7 +323,7 @@ struct TowerArgs {
     int S, nblocks, hc;
 };
 
-template <int C, int NTT, int PREC>
+template <int C, int NTA, int NTB, int PREC>
 __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -393,10 +393,12 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     __syncthreads();
     const int jrow = lane & 15, gq = lane >> 4;
     // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
-    const int tbase = (wave >> 2) * NTT; // waves 4-7 take the second half of the position tiles
-    int vm[NTT];
+    // waves 0-3 own position tiles [0, NTA), waves 4-7 tiles [NTA, NTA+NTB)
+    const bool first = wave < 4;
+    const int tbase = first ? 0 : NTA;
+    int vm[NTA];
 #pragma unroll
-    for (int t = 0; t < NTT; t++) {
+    for (int t = 0; t < NTA; t++) {
         int row = (tbase + t) * 16 + jrow;
         int pos = row % HW, y = pos / W, x = pos - y * W;
         int m = 0;
@@ -411,21 +413,21 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     const int zbase = zu; // multiple of 16 units; the per-lane slot is added per tap
     if constexpr (PREC == 0) {
         const size_t wl = (size_t)C * C * 9;
-        for (int b = 0; b < a.nblocks; b++) {
-            conv_lds_f32<C, NTT>(X4, Y4, a.tw + (size_t)(2 * b) * wl, a.tb + (2 * b) * C, vm, rowbase, zbase, W, R, wave, lane, 0, tbase);
-            __syncthreads();
-            conv_lds_f32<C, NTT>(Y4, X4, a.tw + (size_t)(2 * b + 1) * wl, a.tb + (2 * b + 1) * C, vm, rowbase, zbase, W, R, wave, lane, 1, tbase);
+        for (int l = 0; l < 2 * a.nblocks; l++) {
+            const f32x4 *src = (l & 1) ? Y4 : X4;
+            f32x4 *dst = (l & 1) ? X4 : Y4;
+            if (first) conv_lds_f32<C, NTA>(src, dst, a.tw + (size_t)l * wl, a.tb + l * C, vm, rowbase, zbase, W, R, wave, lane, l & 1, tbase);
+            else conv_lds_f32<C, NTB>(src, dst, a.tw + (size_t)l * wl, a.tb + l * C, vm, rowbase, zbase, W, R, wave, lane, l & 1, tbase);
             __syncthreads();
         }
     } else {
         const f32x4 *tw4 = reinterpret_cast<const f32x4 *>(a.tw);
         const size_t wl = (size_t)C * C * 9 * 2 * 2 / 16; // 16-byte units per layer (hi + lo halves)
-        for (int b = 0; b < a.nblocks; b++) {
-            conv_lds_h3<C, NTT>(X4, Y4, tw4 + (size_t)(2 * b) * wl, a.tb + (2 * b) * C, a.tosc[2 * b], vm, rowbase, zbase, W, R, wave,
-                                lane, 0, a.overflow, tbase);
-            __syncthreads();
-            conv_lds_h3<C, NTT>(Y4, X4, tw4 + (size_t)(2 * b + 1) * wl, a.tb + (2 * b + 1) * C, a.tosc[2 * b + 1], vm, rowbase, zbase,
-                                W, R, wave, lane, 1, a.overflow, tbase);
+        for (int l = 0; l < 2 * a.nblocks; l++) {
+            const f32x4 *src = (l & 1) ? Y4 : X4;
+            f32x4 *dst = (l & 1) ? X4 : Y4;
+            if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase);
+            else conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase);
             __syncthreads();
         }
     }
@@ -712,30 +714,30 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
 }
 
 // launches (or, with attr_only, raises the dynamic-LDS limit of) the instantiation for (C, NTT, PREC)
-template <int C, int NTT>
+template <int C, int NTA, int NTB>
 static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
 {
     const int grid = (max_n + nn->S - 1) / nn->S;
     if constexpr (C >= 32) {
         if (nn->precision == 1) {
             if (attr_only)
-                return hipFuncSetAttribute((const void *)k_tower<C, NTT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
-            hipLaunchKernelGGL((k_tower<C, NTT, 1>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
+                return hipFuncSetAttribute((const void *)k_tower<C, NTA, NTB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
+            hipLaunchKernelGGL((k_tower<C, NTA, NTB, 1>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
             return hipSuccess;
         }
     }
     if (attr_only)
-        return hipFuncSetAttribute((const void *)k_tower<C, NTT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
-    hipLaunchKernelGGL((k_tower<C, NTT, 0>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
+        return hipFuncSetAttribute((const void *)k_tower<C, NTA, NTB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
+    hipLaunchKernelGGL((k_tower<C, NTA, NTB, 0>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
     return hipSuccess;
 }
 template <int C>
 static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
 {
     switch (nn->NTT) {
-    case 2: return tower_inst<C, 2>(nn, s, ta, max_n, attr_only);
-    case 4: return tower_inst<C, 4>(nn, s, ta, max_n, attr_only);
-    default: return tower_inst<C, 7>(nn, s, ta, max_n, attr_only);
+    case 2: return tower_inst<C, 2, 2>(nn, s, ta, max_n, attr_only);
+    case 4: return tower_inst<C, 4, 4>(nn, s, ta, max_n, attr_only);
+    default: return tower_inst<C, 7, 6>(nn, s, ta, max_n, attr_only);
     }
 }
 static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)

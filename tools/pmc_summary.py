@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs (one directory per pass) into profiles/<name>.json.
+
+    python tools/pmc_summary.py gpurun_out/pmc3 profiles/r01_pmc_tower.json
+
+Traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB-like units of
+1024 B; on gfx950 FETCH_SIZE reads one half of the bytes of wide coalesced streams, so the read
+side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def main(src, dst):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for f in sorted(glob.glob(src + "/*/*/*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {"kernels": {}}
+    for k, v in per.items():
+        if k.startswith("__amd"):
+            continue
+        out["kernels"][k] = {c: {"launches": len(x), "mean": sum(x) / len(x)} for c, x in v.items()}
+        out["kernels"][k]["mean_duration_ns_under_pmc"] = sum(dur[k]) / len(dur[k])
+    tower = [k for k in out["kernels"] if k.startswith("k_tower")]
+    if tower:
+        t = out["kernels"][tower[0]]
+        fetch = t.get("FETCH_SIZE", {}).get("mean")
+        write = t.get("WRITE_SIZE", {}).get("mean")
+        if fetch is not None and write is not None:
+            out["traffic_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
+            out["note"] = ("(2*FETCH_SIZE + WRITE_SIZE)*1024 B per k_tower launch (gfx950 FETCH_SIZE correction); the read side "
+                           "is the 5.9 MB of packed weights re-streamed Infinity-Cache -> L2 by each XCD on every pass "
+                           "(weights exceed the 4 MiB L2), not HBM; algorithmic bytes per launch = features in + head "
+                           "activations out + weights once")
+        busy = t.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("mean")
+        gui = t.get("GRBM_GUI_ACTIVE", {}).get("mean")
+        if busy and gui:
+            out["mfma_busy_frac"] = busy / (gui / 8.0 * 1024.0)  # 8 XCDs summed; 256 CUs x 4 SIMDs
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps({k: out.get(k) for k in ("traffic_bytes_per_launch", "mfma_busy_frac")}))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
