@@ -110,7 +110,7 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
         raise SystemExit("engine reported %d slots in error (node pool exhausted?)" % c1["error_slots"])
     m = {k: c1[k] - c0[k] for k in ("expansions", "nn_evals", "sum_path", "terminal_leaves", "moves_played")}
     m.update(dt=dt, ms_total=c1["ms_total"], ms_nn_tower=c1["ms_nn_tower"], pool_high_water=c1["pool_high_water"],
-             nodes_per_slot=eng.cfg.nodes_per_slot or 6 * (args.sims + 2), E=eng.E)
+             nodes_per_slot=eng.cfg.nodes_per_slot or 10 * (args.sims + 2), E=eng.E)
     if dist is not None:
         tdev = torch.tensor([float(m["expansions"]), float(m["nn_evals"]), dt], dtype=torch.float64).cuda()
         mx = tdev.clone()
@@ -120,6 +120,40 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
     else:
         m.update(exp_all=float(m["expansions"]), evals_all=float(m["nn_evals"]), dt_max=dt)
     return eng, m
+
+
+def full_games(args, rank, local_rank, world, torch):
+    """Direct games/s: args.full_games complete games from the empty board (slots refilled as games
+    end), samples fetched, wall clock around everything after engine construction."""
+    from dotsboxesaz_amd.engine import Engine
+    from dotsboxesaz_amd import nn as dnn
+    rows = cols = args.board
+    eng = Engine(rows, cols, args.slots, mcts_num_read=args.sims, noise=(0.8, 0.25), reuse_tree=True,
+                 evaluator=args.evaluator, seed=1000 + rank, device=local_rank, nn_precision=args.precision)
+    if args.evaluator == "resnet":
+        torch.manual_seed(0)
+        model = dnn.ResNetZero(dnn.resnet_params(rows, cols, args.channels, args.blocks))
+        eng.load_state_dict(model.state_dict(), "resnet", **model.shape)
+    eng.sync()
+    t0 = time.perf_counter()
+    eng.selfplay_start(args.full_games, 0)
+    eng.run()
+    got = eng.fetch_samples()
+    dt = time.perf_counter() - t0
+    c = eng.counters()
+    out = {"metric": "selfplay_games_per_sec", "value": c["games_finished"] / dt, "unit": "games/s", "n_gpus": 1,
+           "higher_is_better": True, "data": "synthetic", "seconds": dt, "games": c["games_finished"],
+           "expansions": c["expansions"], "expansions_per_sec": c["expansions"] / dt,
+           "expansions_per_game": c["expansions"] / max(1, c["games_finished"]),
+           "rows": int(len(got["z"])), "rows_per_game": len(got["z"]) / max(1, c["games_finished"]),
+           "mean_path_len": c["sum_path"] / max(1, c["expansions"]),
+           "terminal_leaf_fraction": c["terminal_leaves"] / max(1, c["expansions"]),
+           "pool_high_water": c["pool_high_water"], "steps": c["steps"],
+           "config": {"workload": "%dx%d board, %d complete games on %d slots, %d sims/move, evaluator=%s %dx%d, precision %d"
+                                  % (rows, cols, args.full_games, args.slots, args.sims, args.evaluator, args.blocks,
+                                     args.channels, args.precision)}}
+    print(json.dumps(out), flush=True)
+    eng.close()
 
 
 def tower_roofline(args, m, steps, precision):
@@ -154,6 +188,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-side-run", action="store_true")
+    ap.add_argument("--full-games", type=int, default=0,
+                    help="instead of timing K steps, play this many COMPLETE games from the empty board and report "
+                         "games/s and expansions/game measured directly (one JSON line, metric selfplay_games_per_sec)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,6 +203,9 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.full_games > 0:
+        full_games(args, rank, local_rank, world, torch)
+        return
     eng, m = run_engine(args, args.precision, args.steps, args.warmup, rank, local_rank, world, dist, torch)
     # replay all-gather at iteration end (multi-GPU): whatever finished + a fixed synthetic shard
     gather = None

@@ -179,7 +179,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     g.rows = cfg->rows; g.cols = cfg->cols; g.H = g.rows + 1; g.W = g.cols + 1; g.HW = g.H * g.W;
     g.A = 2 * g.HW; g.AS = (g.A + 3) & ~3; g.B = g.rows * g.cols; g.E = 2 * g.rows * g.cols + g.rows + g.cols;
     g.node_dw = META_DW + 4 * g.AS;
-    g.cap = cfg->nodes_per_slot > 0 ? cfg->nodes_per_slot : 6 * (cfg->mcts_num_read + 2);
+    g.cap = cfg->nodes_per_slot > 0 ? cfg->nodes_per_slot : 10 * (cfg->mcts_num_read + 2);
     if (g.cap < 8) g.cap = 8;
     g.dmax = g.E + 4;
     for (int c = 0; c < g.W; c++) { int i = (1 * g.H + g.rows) * g.W + c; g.sentinel[i >> 6] |= 1ull << (i & 63); }

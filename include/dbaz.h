@@ -54,7 +54,7 @@ typedef struct dbaz_engine dbaz_engine;
 typedef struct {
     int32_t rows, cols;
     int32_t n_slots;        /* concurrent games resident on the GPU */
-    int32_t nodes_per_slot; /* node pool per game; 0 = 6*(mcts_num_read+2) */
+    int32_t nodes_per_slot; /* node pool per game; 0 = 10*(mcts_num_read+2) */
     int32_t mcts_num_read;  /* self_play.mcts.mcts_num_read */
     double cpuct, cpuct_base; /* self_play.mcts.mcts_cpuct */
     double noise_alpha, noise_coeff; /* self_play.noise */
