@@ -84,6 +84,9 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
         torch.manual_seed(0)
         model = dnn.ResNetZero(dnn.resnet_params(rows, cols, args.channels, args.blocks))
         eng.load_state_dict(model.state_dict(), "resnet", **model.shape)
+    elif args.evaluator == "simplenn":
+        torch.manual_seed(0)
+        eng.load_state_dict(dnn.SimpleNN().state_dict(), "simplenn")
     # synthetic mid-game population: slot i starts (i*37 mod 0.7E) random legal plies into a game
     span = max(1, int(0.7 * eng.E))
     eng.selfplay_fastforward((np.arange(args.slots) * 37) % span)
@@ -182,7 +185,7 @@ def main():
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--blocks", type=int, default=20)
-    ap.add_argument("--evaluator", default="resnet", choices=["resnet", "formula", "uniform"])
+    ap.add_argument("--evaluator", default="resnet", choices=["resnet", "simplenn", "formula", "uniform"])
     ap.add_argument("--precision", type=int, default=1,
                     help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)

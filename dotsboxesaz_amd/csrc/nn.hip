@@ -58,6 +58,12 @@ struct NNState {
     int KP = 0, RS4 = 0, ntp = 0, ntv = 0;
     size_t fc_lds = 0;
     float *wv1 = nullptr, *bv1 = nullptr;       // [vf], [1]
+    // SimpleNN
+    float *sn_s0 = nullptr, *sn_t0 = nullptr, *sn_ts = nullptr, *sn_tt = nullptr;
+    float *sn_flat = nullptr, *sn_h1 = nullptr;
+    float *sn_w0 = nullptr, *sn_b0 = nullptr, *sn_ps0 = nullptr, *sn_pt0 = nullptr; // fc0
+    float *sn_w1 = nullptr, *sn_b1 = nullptr, *sn_ps1 = nullptr, *sn_pt1 = nullptr; // fc1
+    size_t sn_lds = 0;
     int S = 1, NT = 1, NTT = 7;                 // samples / position tiles per conv workgroup (NTT: compiled tile count)
     size_t conv_lds = 0;
 };
@@ -76,7 +82,8 @@ struct NNState {
 template <int C, int NTT>
 __device__ __forceinline__ void conv_lds_f32(const f32x4 *__restrict__ src4, f32x4 *dst4, const float *__restrict__ wpk,
                                              const float *__restrict__ bias, const int *vm, int rowbase, int zbase,
-                                             int W, int R, int wave, int lane, int residual, int tbase)
+                                             int W, int R, int wave, int lane, int residual, int tbase,
+                                             const float *post_s = nullptr, const float *post_t = nullptr)
 {
     constexpr int S4 = (C + 8) / 4;  // float4 per LDS row
     constexpr int KC = C / 16;       // 16-cin chunks per tap
@@ -138,6 +145,9 @@ __device__ __forceinline__ void conv_lds_f32(const f32x4 *__restrict__ src4, f32
                 f32x4 v = acc[t] + bv;
                 if (residual) v += dst4[o4];
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                if (post_s) // SimpleNN: BatchNorm FOLLOWS the ReLU (dots_boxes_nn.py:86-90)
+                    v = v * *reinterpret_cast<const f32x4 *>(post_s + ct * 16 + gq * 4) +
+                        *reinterpret_cast<const f32x4 *>(post_t + ct * 16 + gq * 4);
                 dst4[o4] = v;
             }
         }
@@ -165,7 +175,8 @@ union u128h { f32x4 f; f16x8 h; };
 template <int C, int NTT>
 __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
                                             const float *__restrict__ bias, float oscale, const int *vm, int rowbase,
-                                            int zbase, int W, int R, int wave, int lane, int residual, int *overflow, int tbase)
+                                            int zbase, int W, int R, int wave, int lane, int residual, int *overflow, int tbase,
+                                            const float *post_s = nullptr, const float *post_t = nullptr)
 {
     constexpr int S4 = (C + 8) / 4;  // 16-byte units per LDS row
     constexpr int KS = C / 32;       // K=32 steps per tap
@@ -257,7 +268,8 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     float x = fmaxf(v[k], 0.f);
-                    ovf |= x > F16_GUARD;
+                    if (post_s) x = x * post_s[ct * 16 + gq * 4 + k] + post_t[ct * 16 + gq * 4 + k]; // post_t pre-scaled
+                    ovf |= fabsf(x) > F16_GUARD;
                     _Float16 h = (_Float16)x;
                     oh[k] = h;
                     ol[k] = (_Float16)(x - (float)h);
@@ -468,6 +480,183 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 }
 
 // ------------------------------------------------------------------------------------
+// SimpleNN trunk (dots_boxes_nn.py:85-91, 3x3 boards): bn_i(relu(conv_i(x))) for conv0 (3->256)
+// and conv1..conv4 (256->256), all LDS-resident like k_tower.  conv4 is unpadded in the
+// reference (4x4 -> 2x2); it is evaluated as the padded conv and only the four inner positions
+// -- whose taps all lie inside the image, so the two agree exactly -- are gathered into the
+// flatten order x.view(n, -1) = [c*4 + i*2 + j].
+// ------------------------------------------------------------------------------------
+struct SimpleArgs {
+    const float *feat;
+    const int32_t *list, *n_dev;
+    const float *w0, *b0, *s0, *t0; // conv0 [27][C], bias, post affine (t0 unscaled)
+    const float *tw, *tb, *ts, *tt; // conv1..4 packed weights, bias, post scale, post shift
+    const float *tosc;              // f16x3 per-layer output scale
+    float *flat;                    // out [sample][1024]
+    int *overflow;
+    int S;
+};
+
+template <int PREC>
+__global__ void __launch_bounds__(CONV_THREADS, 1) k_simple_trunk(Geo g, SimpleArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int C = 256, NTH = 2;
+    constexpr int STRIDE = C + 8, S4 = STRIDE / 4;
+    const int n = *a.n_dev;
+    const int S = a.S;
+    const int s0 = blockIdx.x * S;
+    if (s0 >= n) return;
+    const int HW = g.HW, W = g.W, H = g.H; // 16, 4, 4
+    const int ns = min(S, n - s0);
+    const int R = ns * HW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int zu = (S * HW * S4 + 15) & ~15;
+    const int img_units = zu + 3 * S4;
+    float *X = lds;
+    float *Y = lds + (size_t)img_units * 4;
+    f32x4 *X4 = reinterpret_cast<f32x4 *>(X);
+    f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
+    bool ovf = false;
+    {
+        const int PW = W + 2, PH = H + 2, PP = 3 * PH * PW;
+        float *pad = Y;
+        float *wl = Y + S * PP;
+        for (int i = tid; i < ns * PP; i += CONV_THREADS) pad[i] = 0.0f;
+        for (int i = tid; i < 27 * C; i += CONV_THREADS) wl[i] = a.w0[i];
+        __syncthreads();
+        for (int i = tid; i < ns * 3 * HW; i += CONV_THREADS) {
+            int sidx = i / (3 * HW), r = i - sidx * 3 * HW;
+            int c = r / HW, p = r - c * HW, y = p / W, x = p - y * W;
+            const int slot = a.list ? a.list[s0 + sidx] : s0 + sidx;
+            pad[sidx * PP + (c * PH + y + 1) * PW + x + 1] = a.feat[(size_t)slot * 3 * HW + r]; // no bn_input in SimpleNN
+        }
+        __syncthreads();
+        for (int i = tid; i < R * (C / 16); i += CONV_THREADS) {
+            const int row = i % R, cq = i / R;
+            const int sidx = row / HW, p = row - sidx * HW, y = p / W, x = p - y * W;
+            const float *pp = pad + sidx * PP;
+            float in27[27];
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) in27[tap * 3 + c] = pp[(c * PH + y + tap / 3) * PW + x + tap % 3];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int co = cq * 16 + q * 4;
+                f32x4 acc = *reinterpret_cast<const f32x4 *>(a.b0 + co);
+#pragma unroll
+                for (int k = 0; k < 27; k++) acc += in27[k] * *reinterpret_cast<const f32x4 *>(wl + k * C + co);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    act_store<C, PREC>(X, row, co + e, fmaxf(acc[e], 0.0f) * a.s0[co + e] + a.t0[co + e], ovf);
+            }
+        }
+        __syncthreads();
+        if (tid < 3 * S4) {
+            X4[zu + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            Y4[zu + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    const int jrow = lane & 15, gq = lane >> 4;
+    const int tbase = (wave < 4) ? 0 : NTH;
+    int vm[NTH];
+#pragma unroll
+    for (int t = 0; t < NTH; t++) {
+        int row = (tbase + t) * 16 + jrow;
+        int pos = row % HW, y = pos / W, x = pos - y * W;
+        int m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
+        }
+        vm[t] = row < R ? m : 0;
+    }
+    const int rowbase = (tbase * 16 + jrow) * S4 + gq;
+    for (int l = 0; l < 4; l++) {
+        const f32x4 *src = (l & 1) ? Y4 : X4;
+        f32x4 *dst = (l & 1) ? X4 : Y4;
+        if constexpr (PREC == 0) {
+            conv_lds_f32<C, NTH>(src, dst, a.tw + (size_t)l * C * C * 9, a.tb + l * C, vm, rowbase, zu, W, R, wave, lane, 0, tbase,
+                                 a.ts + l * C, a.tt + l * C);
+        } else {
+            const size_t wl16 = (size_t)C * C * 9 * 2 * 2 / 16;
+            conv_lds_h3<C, NTH>(src, dst, reinterpret_cast<const f32x4 *>(a.tw) + (size_t)l * wl16, a.tb + l * C, a.tosc[l], vm,
+                                rowbase, zu, W, R, wave, lane, 0, a.overflow, tbase, a.ts + l * C, a.tt + l * C);
+        }
+        __syncthreads();
+    }
+    // after 4 layers the result is back in X; gather the inner 2x2 of every sample
+    for (int i = tid; i < ns * 1024; i += CONV_THREADS) {
+        const int sidx = i >> 10, f = i & 1023, c = f >> 2, q = f & 3;
+        const int row = sidx * HW + (1 + (q >> 1)) * W + 1 + (q & 1);
+        a.flat[(size_t)(s0 + sidx) * 1024 + f] = act_load<C, PREC>(X, row, c);
+    }
+    if (PREC == 1 && ovf) atomicOr(a.overflow, 1);
+}
+
+// Dense layer  out[n][O] = post(relu(in[n][K] . W[O][K]^T + b))  on f32 MFMA, 16 samples per
+// workgroup (same GEMM core as k_head_fc).  dup = 1 writes the result twice per sample
+// ([n][2][O]): the layout k_head_fc expects when both heads read the same vector.
+struct DenseArgs {
+    const int32_t *n_dev;
+    const float *in;        // [n][K]
+    const float *w;         // packed [O/16][K/16][64][4]
+    const float *b, *ps, *pt;
+    float *out;
+    int K, O, RS4, dup;
+};
+
+__global__ void __launch_bounds__(256) k_dense(DenseArgs h)
+{
+    extern __shared__ __attribute__((aligned(16))) float ldsd[];
+    const int n = *h.n_dev;
+    const int j0 = blockIdx.x * 16;
+    if (j0 >= n) return;
+    const int ns = min(16, n - j0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int RS = h.RS4 * 4, K = h.K, KC = K / 16, NJ = h.O / 16;
+    float *act = ldsd;
+    for (int i = tid; i < 16 * K; i += 256) {
+        int sidx = i / K, k = i - sidx * K;
+        act[sidx * RS + k] = sidx < ns ? h.in[(size_t)(j0 + sidx) * K + k] : 0.0f;
+    }
+    __syncthreads();
+    const int jrow = lane & 15, gq = lane >> 4;
+    const f32x4 *act4 = reinterpret_cast<const f32x4 *>(act);
+    for (int job = wave; job < NJ; job += 4) {
+        const f32x4 *wb = reinterpret_cast<const f32x4 *>(h.w) + (size_t)job * KC * 64 + lane;
+        const f32x4 *bb = act4 + jrow * h.RS4 + gq;
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        for (int kc = 0; kc < KC; kc += 2) {
+            const f32x4 a0 = wb[(size_t)kc * 64], a1 = wb[(size_t)(kc + 1) * 64];
+            const f32x4 b0 = bb[kc * 4], b1 = bb[(kc + 1) * 4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc1, 0, 0, 0);
+            }
+        }
+        const f32x4 acc = acc0 + acc1;
+        if (jrow < ns) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = job * 16 + gq * 4 + r;
+                const float v = fmaxf(acc[r] + h.b[o], 0.0f) * h.ps[o] + h.pt[o];
+                if (h.dup) {
+                    h.out[((size_t)(j0 + jrow) * 2) * h.O + o] = v;
+                    h.out[((size_t)(j0 + jrow) * 2 + 1) * h.O + o] = v;
+                } else {
+                    h.out[(size_t)(j0 + jrow) * h.O + o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // heads
 // ------------------------------------------------------------------------------------
 // Head FCs as one batched GEMM on f32 MFMA: a workgroup takes 16 samples;
@@ -485,6 +674,7 @@ struct HeadArgs {
     const float *wv1, *bv1; // value FC1 [vf], [1]
     float *P, *V;
     int K, KP /*K padded to 16*/, RS4 /*LDS row stride, float4 units*/, ntp, ntv, vf, AS;
+    int value_direct; // SimpleNN: value = tanh(value_fc(x)), no hidden layer
 };
 
 __global__ void __launch_bounds__(256) k_head_fc(Geo g, HeadArgs h)
@@ -554,7 +744,7 @@ __global__ void __launch_bounds__(256) k_head_fc(Geo g, HeadArgs h)
         float hv = 0.0f;
         for (int u = lane; u < h.vf; u += 64) hv += fmaxf(l[h.ntp * 16 + u], 0.0f) * h.wv1[u];
         for (int s = 32; s > 0; s >>= 1) hv += __shfl_xor(hv, s);
-        if (lane == 0) h.V[dst] = tanhf(hv + h.bv1[0]);
+        if (lane == 0) h.V[dst] = h.value_direct ? tanhf(l[h.ntp * 16]) : tanhf(hv + h.bv1[0]);
     }
 }
 
@@ -604,7 +794,15 @@ bool nn_ready(const NNState *nn) { return nn && nn->ready; }
 
 int nn_configure(NNState *nn, int kind, int channels, int blocks, int head_channels, int value_fc, std::string &err)
 {
-    if (kind != DBAZ_EVAL_RESNET) { err = "only DBAZ_EVAL_RESNET is implemented in this build"; return DBAZ_EINVAL; }
+    if (kind == DBAZ_EVAL_SIMPLENN) {
+        // hard-wired to 3x3 boards in the reference (fc0 in = 1024, policy_fc out = 32; dots_boxes_nn.py:76,83)
+        if (nn->g.rows != 3 || nn->g.cols != 3) { err = "SimpleNN is defined for 3x3 boards only"; return DBAZ_EINVAL; }
+        nn_free_device(nn);
+        nn->sd.clear();
+        nn->kind = kind; nn->C = 256; nn->Craw = 256; nn->blocks = 0; nn->hc = 0; nn->vf = 1;
+        return DBAZ_OK;
+    }
+    if (kind != DBAZ_EVAL_RESNET) { err = "kind must be DBAZ_EVAL_RESNET or DBAZ_EVAL_SIMPLENN"; return DBAZ_EINVAL; }
     if (channels < 1 || channels > 128) { err = "channels must be in 1..128"; return DBAZ_EINVAL; }
     if (blocks < 0 || head_channels < 1 || value_fc < 1 || value_fc > 64) { err = "bad network shape"; return DBAZ_EINVAL; }
     nn_free_device(nn);
@@ -653,13 +851,18 @@ static bool bn_affine(NNState *nn, const std::string &p, int n, std::vector<doub
 
 // conv3x3 [C][C][3][3] + following BN -> packed fragment order [C/16][9][C/16][64][4]
 static bool pack_conv(NNState *nn, const std::string &conv, const std::string &bn, int C, std::vector<float> &pk_all,
-                      std::vector<float> &bias_all, std::string &err)
+                      std::vector<float> &bias_all, std::string &err, bool fold = true)
 {
     const int Cr = nn->Craw;
     auto w = sd_get(nn, conv + ".weight", (size_t)Cr * Cr * 9, err); if (!w) return false;
     auto b = sd_get(nn, conv + ".bias", Cr, err); if (!b) return false;
     std::vector<double> s, t;
-    if (!bn_affine(nn, bn, Cr, s, t, err)) return false;
+    if (fold) {
+        if (!bn_affine(nn, bn, Cr, s, t, err)) return false;
+    } else {
+        s.assign(Cr, 1.0);
+        t.assign(Cr, 0.0);
+    }
     const int KC = C / 16;
     std::vector<float> pk((size_t)C * C * 9, 0.0f), bias(C, 0.0f);
     for (int ct = 0; ct < C / 16; ct++)
@@ -750,9 +953,141 @@ static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const TowerArgs &ta
     }
 }
 
+// packs a Linear [O][K] for the 16-sample MFMA GEMM: [O/16][K/16][64][4]
+static std::vector<float> pack_dense(const std::vector<float> &w, int O, int K)
+{
+    const int KC = K / 16;
+    std::vector<float> pk((size_t)O * K, 0.0f);
+    for (int job = 0; job < O / 16; job++)
+        for (int kc = 0; kc < KC; kc++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int e = 0; e < 4; e++) {
+                    int o = job * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4) + e;
+                    pk[(((size_t)job * KC + kc) * 64 + lane) * 4 + e] = w[(size_t)o * K + k];
+                }
+    return pk;
+}
+
+static int dense_rs4(int K)
+{
+    int rs4 = K / 4;
+    return ((rs4 + 15) / 16) * 16 + 2;
+}
+
+static int commit_simplenn(NNState *nn, std::string &err)
+{
+    const Geo &g = nn->g;
+    const int C = 256;
+    for (void *p : nn->allocs) (void)hipFree(p);
+    nn->allocs.clear();
+    nn->ready = false;
+    auto f32v = [](const std::vector<double> &d) { return std::vector<float>(d.begin(), d.end()); };
+    // conv0 (3 -> 256) raw + bn0 applied after the ReLU
+    {
+        auto w = sd_get(nn, "conv0.weight", (size_t)C * 27, err); if (!w) return DBAZ_EINVAL;
+        auto b = sd_get(nn, "conv0.bias", C, err); if (!b) return DBAZ_EINVAL;
+        std::vector<double> sc, tc;
+        if (!bn_affine(nn, "bn0", C, sc, tc, err)) return DBAZ_EINVAL;
+        std::vector<float> pk((size_t)27 * C);
+        for (int co = 0; co < C; co++)
+            for (int ci = 0; ci < 3; ci++)
+                for (int tap = 0; tap < 9; tap++) pk[(size_t)(tap * 3 + ci) * C + co] = (*w)[((size_t)co * 3 + ci) * 9 + tap];
+        nn->w0 = nn_upload(nn, pk);
+        nn->b0 = nn_upload(nn, *b);
+        nn->sn_s0 = nn_upload(nn, f32v(sc));
+        nn->sn_t0 = nn_upload(nn, f32v(tc));
+    }
+    // conv1..conv4 raw, post affine from bn1..bn4
+    {
+        std::vector<float> pk_all, bias_all, ps_all, pt_all;
+        nn->osc_host.clear();
+        for (int i = 1; i <= 4; i++) {
+            std::string c = "conv" + std::to_string(i), bnn = "bn" + std::to_string(i);
+            if (!pack_conv(nn, c, bnn, C, pk_all, bias_all, err, false)) return DBAZ_EINVAL;
+            std::vector<double> sc, tc;
+            if (!bn_affine(nn, bnn, C, sc, tc, err)) return DBAZ_EINVAL;
+            for (int k = 0; k < C; k++) {
+                ps_all.push_back((float)sc[k]);
+                pt_all.push_back((float)(tc[k] * (nn->precision == 1 ? (double)ACT_SCALE : 1.0)));
+            }
+        }
+        if (nn->osc_host.empty()) nn->osc_host.assign(4, 1.0f);
+        nn->tw = nn_upload(nn, pk_all);
+        nn->tb = nn_upload(nn, bias_all);
+        nn->sn_ts = nn_upload(nn, ps_all);
+        nn->sn_tt = nn_upload(nn, pt_all);
+        nn->tosc = nn_upload(nn, nn->osc_host);
+        nn->overflow = nn_alloc<int>(nn, 4);
+        if (!nn->tw || !nn->overflow) { err = "hipMalloc failed (SimpleNN weights)"; return DBAZ_EDEVICE; }
+        (void)hipMemset(nn->overflow, 0, 16);
+    }
+    // fc0 / fc1 with BatchNorm1d after the ReLU
+    {
+        auto w0 = sd_get(nn, "fc0.weight", (size_t)512 * 1024, err); if (!w0) return DBAZ_EINVAL;
+        auto b0 = sd_get(nn, "fc0.bias", 512, err); if (!b0) return DBAZ_EINVAL;
+        auto w1 = sd_get(nn, "fc1.weight", (size_t)256 * 512, err); if (!w1) return DBAZ_EINVAL;
+        auto b1 = sd_get(nn, "fc1.bias", 256, err); if (!b1) return DBAZ_EINVAL;
+        std::vector<double> s0, t0, s1, t1;
+        if (!bn_affine(nn, "bn_fc0", 512, s0, t0, err)) return DBAZ_EINVAL;
+        if (!bn_affine(nn, "bn_fc1", 256, s1, t1, err)) return DBAZ_EINVAL;
+        nn->sn_w0 = nn_upload(nn, pack_dense(*w0, 512, 1024));
+        nn->sn_b0 = nn_upload(nn, *b0);
+        nn->sn_ps0 = nn_upload(nn, f32v(s0));
+        nn->sn_pt0 = nn_upload(nn, f32v(t0));
+        nn->sn_w1 = nn_upload(nn, pack_dense(*w1, 256, 512));
+        nn->sn_b1 = nn_upload(nn, *b1);
+        nn->sn_ps1 = nn_upload(nn, f32v(s1));
+        nn->sn_pt1 = nn_upload(nn, f32v(t1));
+    }
+    // heads: policy_fc [32][256], value_fc [1][256] in k_head_fc's job layout
+    {
+        auto wp = sd_get(nn, "policy_fc.weight", (size_t)32 * 256, err); if (!wp) return DBAZ_EINVAL;
+        auto bp = sd_get(nn, "policy_fc.bias", 32, err); if (!bp) return DBAZ_EINVAL;
+        auto wv = sd_get(nn, "value_fc.weight", 256, err); if (!wv) return DBAZ_EINVAL;
+        auto bv = sd_get(nn, "value_fc.bias", 1, err); if (!bv) return DBAZ_EINVAL;
+        const int K = 256, KC = K / 16, ntp = 2, ntv = 1, NJ = 3;
+        std::vector<float> pk((size_t)NJ * KC * 64 * 4, 0.0f), bias((size_t)NJ * 16, 0.0f);
+        for (int job = 0; job < NJ; job++)
+            for (int kc = 0; kc < KC; kc++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 4; e++) {
+                        int o = (job < ntp ? job : 0) * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4) + e;
+                        float v = 0.0f;
+                        if (job < ntp) v = (*wp)[(size_t)o * K + k];
+                        else if ((lane & 15) == 0) v = (*wv)[k];
+                        pk[(((size_t)job * KC + kc) * 64 + lane) * 4 + e] = v;
+                    }
+        for (int i = 0; i < 32; i++) bias[i] = (*bp)[i];
+        bias[32] = (*bv)[0];
+        nn->wfc = nn_upload(nn, pk);
+        nn->bfc = nn_upload(nn, bias);
+        std::vector<float> one(1, 0.0f);
+        nn->wv1 = nn_upload(nn, one);
+        nn->bv1 = nn_upload(nn, one);
+        nn->KP = K; nn->ntp = ntp; nn->ntv = ntv; nn->RS4 = dense_rs4(K);
+        nn->fc_lds = ((size_t)16 * nn->RS4 * 4 + (size_t)16 * (NJ * 16 + 1)) * 4;
+    }
+    nn->sn_flat = nn_alloc<float>(nn, (size_t)nn->max_batch * 1024);
+    nn->sn_h1 = nn_alloc<float>(nn, (size_t)nn->max_batch * 512);
+    nn->hact = nn_alloc<float>(nn, (size_t)nn->max_batch * 2 * 256);
+    if (!nn->sn_flat || !nn->sn_h1 || !nn->hact || !nn->wfc) { err = "hipMalloc failed (SimpleNN buffers)"; return DBAZ_EDEVICE; }
+    // LDS: two images of S*16 rows x 264 dwords (+ zero regions); S = 4 -> 141 KB
+    const size_t s4 = (C + 8) / 4;
+    nn->S = 4;
+    nn->sn_lds = 2 * ((((size_t)nn->S * g.HW * s4 + 15) & ~(size_t)15) + 3 * s4) * 16;
+    hipError_t he = hipFuncSetAttribute(nn->precision == 1 ? (const void *)k_simple_trunk<1> : (const void *)k_simple_trunk<0>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->sn_lds);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)k_dense, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * dense_rs4(1024) * 16);
+    if (he == hipSuccess) he = hipFuncSetAttribute((const void *)k_head_fc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->fc_lds);
+    if (he != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); return DBAZ_EDEVICE; }
+    nn->ready = true;
+    return DBAZ_OK;
+}
+
 int nn_commit(NNState *nn, hipStream_t s, std::string &err)
 {
     (void)s;
+    if (nn->kind == DBAZ_EVAL_SIMPLENN) return commit_simplenn(nn, err);
     if (nn->kind != DBAZ_EVAL_RESNET) { err = "dbaz_nn_configure not called"; return DBAZ_ESTATE; }
     const Geo &g = nn->g;
     const int C = nn->C, Cr = nn->Craw, hc = nn->hc, vf = nn->vf, HW = g.HW, A = g.A, K = hc * HW;
@@ -886,6 +1221,31 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     const Geo &g = nn->g;
     const int hc = nn->hc, HW = g.HW;
     if (max_n > nn->max_batch) max_n = nn->max_batch;
+    if (nn->kind == DBAZ_EVAL_SIMPLENN) {
+        SimpleArgs sa;
+        sa.feat = feat; sa.list = list_dev; sa.n_dev = n_dev; sa.w0 = nn->w0; sa.b0 = nn->b0; sa.s0 = nn->sn_s0; sa.t0 = nn->sn_t0;
+        sa.tw = nn->tw; sa.tb = nn->tb; sa.ts = nn->sn_ts; sa.tt = nn->sn_tt; sa.tosc = nn->tosc; sa.flat = nn->sn_flat;
+        sa.overflow = nn->overflow; sa.S = nn->S;
+        if (ev_begin) (void)hipEventRecord(ev_begin, s);
+        const int grid = (max_n + nn->S - 1) / nn->S;
+        if (nn->precision == 1) hipLaunchKernelGGL(k_simple_trunk<1>, dim3(grid), dim3(CONV_THREADS), nn->sn_lds, s, g, sa);
+        else hipLaunchKernelGGL(k_simple_trunk<0>, dim3(grid), dim3(CONV_THREADS), nn->sn_lds, s, g, sa);
+        if (ev_end) (void)hipEventRecord(ev_end, s);
+        DenseArgs d0;
+        d0.n_dev = n_dev; d0.in = nn->sn_flat; d0.w = nn->sn_w0; d0.b = nn->sn_b0; d0.ps = nn->sn_ps0; d0.pt = nn->sn_pt0;
+        d0.out = nn->sn_h1; d0.K = 1024; d0.O = 512; d0.RS4 = dense_rs4(1024); d0.dup = 0;
+        hipLaunchKernelGGL(k_dense, dim3((max_n + 15) / 16), dim3(256), (size_t)16 * d0.RS4 * 16, s, d0);
+        DenseArgs d1;
+        d1.n_dev = n_dev; d1.in = nn->sn_h1; d1.w = nn->sn_w1; d1.b = nn->sn_b1; d1.ps = nn->sn_ps1; d1.pt = nn->sn_pt1;
+        d1.out = nn->hact; d1.K = 512; d1.O = 256; d1.RS4 = dense_rs4(512); d1.dup = 1;
+        hipLaunchKernelGGL(k_dense, dim3((max_n + 15) / 16), dim3(256), (size_t)16 * d1.RS4 * 16, s, d1);
+        HeadArgs ha;
+        ha.list = list_dev; ha.n_dev = n_dev; ha.hact = nn->hact; ha.wfc = nn->wfc; ha.bfc = nn->bfc; ha.wv1 = nn->wv1; ha.bv1 = nn->bv1;
+        ha.P = P; ha.V = V; ha.K = 256; ha.KP = 256; ha.RS4 = nn->RS4; ha.ntp = nn->ntp; ha.ntv = nn->ntv; ha.vf = 0; ha.AS = AS;
+        ha.value_direct = 1;
+        hipLaunchKernelGGL(k_head_fc, dim3((max_n + 15) / 16), dim3(256), nn->fc_lds, s, g, ha);
+        return;
+    }
     TowerArgs ta;
     ta.feat = feat; ta.list = list_dev; ta.n_dev = n_dev; ta.in_s = nn->in_s; ta.in_t = nn->in_t; ta.w0 = nn->w0; ta.b0 = nn->b0;
     ta.tw = nn->tw; ta.tb = nn->tb; ta.tosc = nn->tosc; ta.hw = nn->hw; ta.hb = nn->hb; ta.hact = nn->hact;
@@ -896,6 +1256,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     HeadArgs ha;
     ha.list = list_dev; ha.n_dev = n_dev; ha.hact = nn->hact; ha.wfc = nn->wfc; ha.bfc = nn->bfc; ha.wv1 = nn->wv1; ha.bv1 = nn->bv1;
     ha.P = P; ha.V = V; ha.K = hc * HW; ha.KP = nn->KP; ha.RS4 = nn->RS4; ha.ntp = nn->ntp; ha.ntv = nn->ntv; ha.vf = nn->vf; ha.AS = AS;
+    ha.value_direct = 0;
     hipLaunchKernelGGL(k_head_fc, dim3((max_n + 15) / 16), dim3(256), nn->fc_lds, s, g, ha);
 }
 
@@ -903,6 +1264,8 @@ double nn_flops_per_sample(const NNState *nn)
 {
     // 2*MAC of conv + FC layers: conv0, 2*blocks tower convs, head convs, FCs
     const Geo &g = nn->g;
+    if (nn->kind == DBAZ_EVAL_SIMPLENN) // conv0 + 3 padded convs + the unpadded conv4 + FCs (62.89 MFLOP)
+        return 2.0 * (16 * 27 * 256 + 3.0 * 16 * 2304 * 256 + 4 * 2304 * 256 + 1024 * 512 + 512 * 256 + 256 * 33);
     const double HW = g.HW, C = nn->Craw, hc = nn->hc, K = hc * HW;
     double f = 2.0 * HW * 27 * C + 2.0 * nn->blocks * 2.0 * HW * 9 * C * C;
     f += 2.0 * 2.0 * HW * C * hc + 2.0 * K * g.A + 2.0 * K * nn->vf + 2.0 * nn->vf;

@@ -81,6 +81,38 @@ class ResNetZero(nn.Module):
         self.load_state_dict(torch.load(fn, map_location="cpu", weights_only=True)["model_dict"])
 
 
+class SimpleNN(nn.Module):
+    """Reference: dots_boxes/dots_boxes_nn.py:61-105 (3x3 boards only).  Weight container."""
+
+    kind = "simplenn"
+    shape = {}
+
+    def __init__(self, params=None, n_ch=256):
+        super().__init__()
+        self.params = params
+        self.conv0 = nn.Conv2d(3, n_ch, 3, padding=1)
+        self.bn0 = nn.BatchNorm2d(n_ch)
+        for i in (1, 2, 3):
+            setattr(self, "conv%d" % i, nn.Conv2d(n_ch, n_ch, 3, padding=1))
+            setattr(self, "bn%d" % i, nn.BatchNorm2d(n_ch))
+        self.conv4 = nn.Conv2d(n_ch, n_ch, 3, padding=0)
+        self.bn4 = nn.BatchNorm2d(n_ch)
+        self.fc0 = nn.Linear(1024, 512)
+        self.bn_fc0 = nn.BatchNorm1d(512)
+        self.fc1 = nn.Linear(512, 256)
+        self.bn_fc1 = nn.BatchNorm1d(256)
+        self.value_fc = nn.Linear(256, 1)
+        self.policy_fc = nn.Linear(256, 32)
+
+    def forward(self, x):
+        raise RuntimeError("SimpleNN is a weight container on this path: evaluate through "
+                           "NeuralNetWrapper.predict_sync (HIP engine); there is no torch fallback")
+
+    def load_parameters(self, generation, to_device=None):
+        fn = _get(_get(self.params, "nn"), "chkpts_filename").format(generation)
+        self.load_state_dict(torch.load(fn, map_location="cpu", weights_only=True)["model_dict"])
+
+
 def resnet_params(rows, cols, channels=64, blocks=20, head_channels=16, value_fc=8):
     """The shipped `resnet` configuration (configuration.py:134-156) resized to a rows x cols board."""
     H, W = rows + 1, cols + 1

@@ -136,3 +136,59 @@ def test_f16x3_reports_range_overflow():
     with pytest.raises(_lib.DbazError):
         e.predict(np.ones((2, 3, 4, 4), np.float32))
     e.close()
+
+
+# ---------------------------------------------------------------- SimpleNN (row N2)
+def simple_engine(model, precision, n_slots=64):
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(3, 3, n_slots, mcts_num_read=8, evaluator="simplenn", nn_precision=precision)
+    e.load_state_dict(model.state_dict(), "simplenn")
+    return e
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_simplenn_golden_and_torch(golden_nn, precision):
+    """dots_boxes_nn.SimpleNN (BN after ReLU, unpadded conv4, BatchNorm1d FCs) vs the reference's
+    golden outputs (seed-regenerated weights) and the torch restatement."""
+    g = golden_nn
+    torch.manual_seed(0)
+    m = nn_ref.SimpleNNRef()
+    nn_ref.randomize_bn(m, 3)
+    e = simple_engine(m, precision)
+    p, v = e.predict(g["simple_X"])
+    cs = nn_ref.state_dict_checksum(m)
+    if abs(cs - float(g["simple_checksum"])) <= 1e-6 * cs:
+        assert np.abs(p - g["simple_p"]).max() < TOL and np.abs(v - g["simple_v"]).max() < TOL
+    rng = np.random.RandomState(1)
+    X = rng.randint(0, 2, size=(77, 3, 4, 4)).astype(np.float32)
+    X[:, 2] = rng.randint(-1, 10, size=(77, 1, 1))
+    p, v = e.predict(X)
+    pr, vr = nn_ref.predict_sync(m, X)
+    err = max(np.abs(p - pr).max(), np.abs(v - vr).max())
+    print("SimpleNN precision %d max abs err %.3g" % (precision, err))
+    assert err < 2e-5 and p.shape == (77, 32) and v.shape == (77, 1)
+    p1, v1 = e.predict(X[5:6])
+    assert np.array_equal(p1[0], p[5]) and np.array_equal(v1[0], v[5])
+    e.close()
+
+
+def test_simplenn_rejects_other_boards_and_plays():
+    from dotsboxesaz_amd import _lib
+    from dotsboxesaz_amd.engine import Engine
+    from dotsboxesaz_amd import nn as dnn
+    e = Engine(6, 6, 4, evaluator="simplenn")
+    with pytest.raises(_lib.DbazError):
+        e.load_state_dict({}, "simplenn")
+    e.close()
+    torch.manual_seed(1)
+    model = dnn.SimpleNN()
+    ref = nn_ref.SimpleNNRef()
+    ref.load_state_dict(model.state_dict(), strict=True)  # reference key names
+    e = Engine(3, 3, 16, mcts_num_read=20, noise=(0.8, 0.25), evaluator="simplenn", seed=2)
+    e.load_state_dict(model.state_dict(), "simplenn")
+    e.selfplay_start(16, 0)
+    e.run()
+    c = e.counters()
+    got = e.fetch_samples()
+    assert c["games_finished"] == 16 and c["error_slots"] == 0 and len(got["z"]) >= 16 * 9
+    e.close()
