@@ -69,6 +69,9 @@ static int set_error(dbaz_engine *e, int code, const char *fmt, ...)
 
 extern "C" const char *dbaz_last_error(const dbaz_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 extern "C" int dbaz_version(void) { return 1; }
+int nn_read_stamps(NNState *nn, unsigned long long *out, int n_wg);
+// diagnostic builds (-DDBAZ_STAMP) only; not part of include/dbaz.h
+extern "C" int dbaz_debug_read_stamps(dbaz_engine *e, unsigned long long *out, int n_wg);
 
 template <typename T>
 static int dmalloc(dbaz_engine *e, T **p, size_t count, bool zero = true)
@@ -938,6 +941,13 @@ extern "C" int dbaz_fetch_samples(dbaz_engine *e, int32_t max_rows, int32_t *n_r
         if (played) played[r] = m.played;
     }
     return DBAZ_OK;
+}
+
+extern "C" int dbaz_debug_read_stamps(dbaz_engine *e, unsigned long long *out, int n_wg)
+{
+    if (!e) return DBAZ_EINVAL;
+    (void)hipStreamSynchronize(e->stream);
+    return nn_read_stamps(e->nn, out, n_wg) == 0 ? DBAZ_OK : DBAZ_ESTATE;
 }
 
 extern "C" int dbaz_replay_rows_dev(dbaz_engine *e, void **rows_dev, int32_t *n_rows, int32_t *row_bytes)

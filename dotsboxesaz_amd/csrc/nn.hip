@@ -19,6 +19,7 @@
 // out-of-image taps read a shared zero row.  The accumulator layout puts 4 consecutive
 // couts of one position in each lane, so the epilogue (bias, residual, ReLU) is float4.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -31,12 +32,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CONV_THREADS 512 // 8 waves: two per SIMD, wave = (cout tile, half of the position tiles)
 #define MAXT 13 // position tiles (16 rows each) per workgroup
-
-struct ConvLayer {
-    float *w = nullptr;    // packed [C/16][9][C/16][64][4]
-    float *bias = nullptr; // [C]  (conv bias with BN folded)
-    float *post_s = nullptr, *post_t = nullptr; // SimpleNN: affine applied AFTER ReLU
-};
 
 struct NNState {
     Geo g;
@@ -51,6 +46,7 @@ struct NNState {
     float *w0 = nullptr, *b0 = nullptr;         // conv0 [9][3][C], [C]
     float *tw = nullptr, *tb = nullptr;         // tower: packed weights [2*blocks][C*C*9], bias [2*blocks][C]
     float *tosc = nullptr;                      // f16x3: per-layer output scale 2^-(sw+ACT_SHIFT)
+    unsigned long long *stamp_out = nullptr;    // diagnostic build (-DDBAZ_STAMP) only
     int *overflow = nullptr;                    // f16x3: set when an activation left f16's range
     float *hw = nullptr, *hb = nullptr;         // head conv1x1: [2*hc][C], [2*hc]
     float *hact = nullptr;                      // [batch][2][hc*HW]
@@ -172,12 +168,43 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 union u128h { f32x4 f; f16x8 h; };
 
+#ifdef DBAZ_STAMP
+// diagnostic build only (never shipped): per-wave cycle sums of the layer phases
+#define STAMP(var)                                                                      \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
+// first two weight steps of a layer, fetched BEFORE the previous layer's epilogue and barrier so
+// that the L2 latency of a layer's restart is hidden
+struct WPre { f32x4 h0, l0, h1, l1; };
+
+template <int C>
+__device__ __forceinline__ void wpre_load(WPre &pre, const f32x4 *wpk_layer, int wave, int lane)
+{
+    constexpr int N = 9 * (C / 32);
+    const f32x4 *wb = wpk_layer + (size_t)(wave & 3) * N * 2 * 64 + lane;
+    pre.h0 = wb[0];
+    pre.l0 = wb[64];
+    pre.h1 = wb[128];
+    pre.l1 = wb[192];
+}
+
 template <int C, int NTT>
 __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
                                             const float *__restrict__ bias, float oscale, const int *vm, int rowbase,
                                             int zbase, int W, int R, int wave, int lane, int residual, int *overflow, int tbase,
-                                            const float *post_s = nullptr, const float *post_t = nullptr)
+                                            const float *post_s, const float *post_t, WPre &pre, const f32x4 *next_wpk,
+                                            unsigned long long *stamps = nullptr)
 {
+
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)stamps;
     constexpr int S4 = (C + 8) / 4;  // 16-byte units per LDS row
     constexpr int KS = C / 32;       // K=32 steps per tap
     constexpr int LO = C / 8;        // unit offset of the lo halves inside a row
@@ -204,9 +231,12 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
 #pragma unroll
         for (int t = 0; t < NTT; t++)
             ab[t] = ((vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4) * 16;
-        a_h[0].f = wbase[0];
-        a_l[0].f = wbase[64];
-        if (N > 1) {
+        STAMP(t0);
+        if (ct == (wave & 3)) { // first cout tile of the layer: fragments were prefetched across the barrier
+            a_h[0].f = pre.h0; a_l[0].f = pre.l0; a_h[1].f = pre.h1; a_l[1].f = pre.l1;
+        } else {
+            a_h[0].f = wbase[0];
+            a_l[0].f = wbase[64];
             a_h[1].f = wbase[128];
             a_l[1].f = wbase[192];
         }
@@ -214,6 +244,7 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
         for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4);
 #pragma unroll
         for (int t = 0; t < NTT; t++) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + LO * 16);
+        STAMP(t1);
 #pragma unroll
         for (int i = 0; i < N; i++) {
             const int cur = i % 3, pre = (i + 2) % 3;
@@ -248,36 +279,74 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- epilogue: scale back, bias, residual, ReLU, split into halves
+        STAMP(t2);
+        // the bias is fetched BEFORE the cross-barrier weight prefetch: loads return in order, so a
+        // bias load issued after it would make the epilogue wait for the prefetch
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + ct * 16 + gq * 4);
+        asm volatile("" ::"v"(bv));
+        __builtin_amdgcn_sched_barrier(0);
+        if (next_wpk && ct + 4 >= C / 16) wpre_load<C>(pre, next_wpk, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue: scale back, bias, residual, ReLU, split into halves.
+        // All residual reads are issued first (one LDS round trip for the whole wave, not one per
+        // tile); the (hi, lo) split uses gfx950's packed round-to-nearest converts; one running max
+        // replaces per-value range checks.
         _Float16 *dsth = reinterpret_cast<_Float16 *>(dst4);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 rh[NTT], rl[NTT];
+        if (residual) {
+#pragma unroll
+            for (int t = 0; t < NTT; t++) {
+                const int row = min((tbase + t) * 16 + jrow, R - 1);
+                const _Float16 *ph = dsth + (size_t)row * (S4 * 8) + ct * 16 + gq * 4;
+                rh[t] = *reinterpret_cast<const u32x2 *>(ph);
+                rl[t] = *reinterpret_cast<const u32x2 *>(ph + C);
+            }
+        }
+        float vmax = 0.0f;
 #pragma unroll
         for (int t = 0; t < NTT; t++) {
             const int row = (tbase + t) * 16 + jrow;
+            f32x4 v = acc[t] * oscale + bv; // activation-scaled: value * 2^ACT_SHIFT
+            if (residual) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                union { unsigned int u; h2 h; } c0, c1, d0, d1;
+                c0.u = rh[t][0]; c1.u = rh[t][1]; d0.u = rl[t][0]; d1.u = rl[t][1];
+                v[0] += (float)c0.h[0] + (float)d0.h[0];
+                v[1] += (float)c0.h[1] + (float)d0.h[1];
+                v[2] += (float)c1.h[0] + (float)d1.h[0];
+                v[3] += (float)c1.h[1] + (float)d1.h[1];
+            }
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            if (post_s) { // SimpleNN: BatchNorm follows the ReLU; post_t is pre-scaled
+                v = v * *reinterpret_cast<const f32x4 *>(post_s + ct * 16 + gq * 4) +
+                    *reinterpret_cast<const f32x4 *>(post_t + ct * 16 + gq * 4);
+                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            } else {
+                vmax = fmaxf(vmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            }
+            // hi = rn_f16(v), lo = rn_f16(v - hi) on packed pairs: v_cvt_pk_f16_f32 / v_pk_add_f32
+            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            union { h2v h[2]; u32x2 u; } oh, ol;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const f2v x = {v[2 * q], v[2 * q + 1]};
+                const h2v h = __builtin_convertvector(x, h2v);
+                oh.h[q] = h;
+                ol.h[q] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
+            }
             if (row < R) {
                 _Float16 *ph = dsth + (size_t)row * (S4 * 8) + ct * 16 + gq * 4;
-                _Float16 *pl = ph + C;
-                f32x4 v = acc[t] * oscale + bv; // activation-scaled: value * 2^ACT_SHIFT
-                if (residual) {
-                    const f16x4 rh = *reinterpret_cast<const f16x4 *>(ph);
-                    const f16x4 rl = *reinterpret_cast<const f16x4 *>(pl);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v[k] += (float)rh[k] + (float)rl[k];
-                }
-                f16x4 oh, ol;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    float x = fmaxf(v[k], 0.f);
-                    if (post_s) x = x * post_s[ct * 16 + gq * 4 + k] + post_t[ct * 16 + gq * 4 + k]; // post_t pre-scaled
-                    ovf |= fabsf(x) > F16_GUARD;
-                    _Float16 h = (_Float16)x;
-                    oh[k] = h;
-                    ol[k] = (_Float16)(x - (float)h);
-                }
-                *reinterpret_cast<f16x4 *>(ph) = oh;
-                *reinterpret_cast<f16x4 *>(pl) = ol;
+                *reinterpret_cast<u32x2 *>(ph) = oh.u;
+                *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
             }
         }
+        ovf |= vmax > F16_GUARD;
+        STAMP(t3);
+#ifdef DBAZ_STAMP
+        if (stamps) { stamps[0] += t1 - t0; stamps[1] += t2 - t1; stamps[2] += t3 - t2; }
+#endif
     }
     if (ovf) atomicOr(overflow, 1);
 }
@@ -333,6 +402,7 @@ struct TowerArgs {
     float *hact;             // out: [sample][2*hc*HW]
     int *overflow;
     int S, nblocks, hc;
+    unsigned long long *stamp_out; // diagnostic build only
 };
 
 template <int C, int NTA, int NTB, int PREC>
@@ -348,7 +418,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     const int HW = g.HW, W = g.W, H = g.H;
     const int ns = min(S, n - s0);
     const int R = ns * HW;           // valid rows in this workgroup
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NTHR = blockDim.x;
     // Zero REGION (3 rows, starting at a multiple of 16 float4 units) behind the S*HW rows of each
     // image: a lane whose tap falls outside the board reads the zero whose bank slot equals the
     // slot of its natural address, so out-of-image lanes never collide with in-image lanes of
@@ -365,10 +435,10 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         const int PW = W + 2, PH = H + 2, PP = 3 * PH * PW;
         float *pad = Y;               // [ns][3][PH][PW]
         float *wl = Y + S * PP;       // [27][C]
-        for (int i = tid; i < ns * PP; i += CONV_THREADS) pad[i] = 0.0f;
-        for (int i = tid; i < 27 * C; i += CONV_THREADS) wl[i] = a.w0[i];
+        for (int i = tid; i < ns * PP; i += NTHR) pad[i] = 0.0f;
+        for (int i = tid; i < 27 * C; i += NTHR) wl[i] = a.w0[i];
         __syncthreads();
-        for (int i = tid; i < ns * 3 * HW; i += CONV_THREADS) {
+        for (int i = tid; i < ns * 3 * HW; i += NTHR) {
             int sidx = i / (3 * HW), r = i - sidx * 3 * HW;
             int c = r / HW, p = r - c * HW, y = p / W, x = p - y * W;
             const int slot = a.list ? a.list[s0 + sidx] : s0 + sidx;
@@ -377,7 +447,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         __syncthreads();
         // one work item = (row, 16 couts): its 27 inputs are read once, the weights are
         // broadcast reads (16 lanes share an address)
-        for (int i = tid; i < R * (C / 16); i += CONV_THREADS) {
+        for (int i = tid; i < R * (C / 16); i += NTHR) {
             const int row = i % R, cq = i / R;
             const int sidx = row / HW, p = row - sidx * HW, y = p / W, x = p - y * W;
             const float *pp = pad + sidx * PP;
@@ -435,20 +505,40 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     } else {
         const f32x4 *tw4 = reinterpret_cast<const f32x4 *>(a.tw);
         const size_t wl = (size_t)C * C * 9 * 2 * 2 / 16; // 16-byte units per layer (hi + lo halves)
-        for (int l = 0; l < 2 * a.nblocks; l++) {
+        const int NL = 2 * a.nblocks;
+        WPre pre;
+        if (NL > 0) wpre_load<C>(pre, tw4, wave, lane);
+        unsigned long long stamps[4] = {0, 0, 0, 0};
+        unsigned long long tb0 = 0, tb1 = 0, tk0 = 0, tk1 = 0;
+        (void)tb0; (void)tb1; (void)tk0; (void)tk1;
+        STAMP(tk0);
+        for (int l = 0; l < NL; l++) {
             const f32x4 *src = (l & 1) ? Y4 : X4;
             f32x4 *dst = (l & 1) ? X4 : Y4;
-            if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase);
-            else conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase);
+            const f32x4 *nxt = l + 1 < NL ? tw4 + (size_t)(l + 1) * wl : nullptr;
+            if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase, nullptr, nullptr, pre, nxt, stamps);
+            else conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase, nullptr, nullptr, pre, nxt, stamps);
+            STAMP(tb0);
             __syncthreads();
+            STAMP(tb1);
+#ifdef DBAZ_STAMP
+            stamps[3] += tb1 - tb0;
+#endif
         }
+#ifdef DBAZ_STAMP
+        STAMP(tk1);
+        if (a.stamp_out && lane == 0) {
+            unsigned long long *o = a.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 5;
+            o[0] = stamps[0]; o[1] = stamps[1]; o[2] = stamps[2]; o[3] = stamps[3]; o[4] = tk1 - tk0;
+        }
+#endif
     }
     // ---- head conv1x1 (both heads), results staged in Y as [sample][oc][pos] and written out coalesced
     {
         const int OC = 2 * a.hc;
         float *wl = Y;                         // [OC][C+4]
         float *stage = Y + OC * (C + 4);       // [ns][OC][HW]
-        for (int i = tid; i < OC * C; i += CONV_THREADS) {
+        for (int i = tid; i < OC * C; i += NTHR) {
             int o = i / C, c = i - o * C;
             wl[o * (C + 4) + c] = a.hw[i];
         }
@@ -474,7 +564,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         }
         __syncthreads();
         float *o = a.hact + (size_t)s0 * OC * HW;
-        for (int i = tid; i < ns * OC * HW; i += CONV_THREADS) o[i] = stage[i];
+        for (int i = tid; i < ns * OC * HW; i += NTHR) o[i] = stage[i];
     }
     if (PREC == 1 && ovf) atomicOr(a.overflow, 1);
 }
@@ -583,8 +673,11 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_simple_trunk(Geo g, SimpleA
                                  a.ts + l * C, a.tt + l * C);
         } else {
             const size_t wl16 = (size_t)C * C * 9 * 2 * 2 / 16;
-            conv_lds_h3<C, NTH>(src, dst, reinterpret_cast<const f32x4 *>(a.tw) + (size_t)l * wl16, a.tb + l * C, a.tosc[l], vm,
-                                rowbase, zu, W, R, wave, lane, 0, a.overflow, tbase, a.ts + l * C, a.tt + l * C);
+            const f32x4 *tw4 = reinterpret_cast<const f32x4 *>(a.tw);
+            WPre pre;
+            wpre_load<C>(pre, tw4 + (size_t)l * wl16, wave, lane);
+            conv_lds_h3<C, NTH>(src, dst, tw4 + (size_t)l * wl16, a.tb + l * C, a.tosc[l], vm, rowbase, zu, W, R, wave, lane, 0,
+                                a.overflow, tbase, a.ts + l * C, a.tt + l * C, pre, nullptr);
         }
         __syncthreads();
     }
@@ -1133,6 +1226,10 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         nn->overflow = nn_alloc<int>(nn, 4);
         if (!nn->tw || !nn->tb || !nn->tosc || !nn->overflow) { err = "hipMalloc failed (tower weights)"; return DBAZ_EDEVICE; }
         (void)hipMemset(nn->overflow, 0, 16);
+#ifdef DBAZ_STAMP
+        nn->stamp_out = nn_alloc<unsigned long long>(nn, (size_t)nn->max_batch * 8 * 5);
+        (void)hipMemset(nn->stamp_out, 0, (size_t)nn->max_batch * 8 * 5 * 8);
+#endif
     }
     // heads: conv1x1 + BN folded, rows [policy hc | value hc]
     {
@@ -1250,6 +1347,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     ta.feat = feat; ta.list = list_dev; ta.n_dev = n_dev; ta.in_s = nn->in_s; ta.in_t = nn->in_t; ta.w0 = nn->w0; ta.b0 = nn->b0;
     ta.tw = nn->tw; ta.tb = nn->tb; ta.tosc = nn->tosc; ta.hw = nn->hw; ta.hb = nn->hb; ta.hact = nn->hact;
     ta.overflow = nn->overflow; ta.S = nn->S; ta.nblocks = nn->blocks; ta.hc = hc;
+    ta.stamp_out = nn->stamp_out;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     (void)tower_dispatch(nn, s, ta, max_n, false);
     if (ev_end) (void)hipEventRecord(ev_end, s);
@@ -1273,6 +1371,13 @@ double nn_flops_per_sample(const NNState *nn)
 }
 
 const char *nn_tower_kernel_name(const NNState *nn) { (void)nn; return "k_tower"; }
+
+// diagnostic build: copies the stamp sums of the last launch to the host
+int nn_read_stamps(NNState *nn, unsigned long long *out, int n_wg)
+{
+    if (!nn || !nn->stamp_out) return -1;
+    return (int)hipMemcpy(out, nn->stamp_out, (size_t)n_wg * 8 * 5 * 8, hipMemcpyDeviceToHost);
+}
 
 int nn_overflowed(NNState *nn)
 {

@@ -166,3 +166,29 @@ def test_output_buffer_backpressure():
         r = np.nonzero(got["game_idx"] == gi)[0]
         assert np.array_equal(got["move_idx"][r], np.arange(len(r)))
     e.close()
+
+
+def test_replay_rows_stay_in_hbm_and_match_fetch():
+    """dbaz_replay_rows_dev: the packed rows the RCCL all-gather ships (RowMeta | x | visits),
+    wrapped zero-copy as a torch tensor through __cuda_array_interface__, equal fetch_samples()."""
+    import torch
+    from dotsboxesaz_amd.engine import Engine
+    from dotsboxesaz_amd.self_play import _DevBuf
+    e = Engine(3, 3, 8, mcts_num_read=20, evaluator="formula", seed=9)
+    e.selfplay_start(8, 0)
+    e.run()
+    ptr, n, rb = e.replay_rows_dev()
+    assert n > 0 and rb == (28 + 48 * 2 + 32 * 4 + 7) // 8 * 8
+    rows = torch.as_tensor(_DevBuf(ptr, n * rb), device=torch.device("cuda", 0)).view(n, rb).cpu().numpy()
+    got = e.fetch_samples()
+    assert len(got["z"]) == n
+    meta = rows[:, :28].copy()
+    game = meta[:, 0:4].copy().view(np.int32).ravel()
+    move_idx = meta[:, 4:6].copy().view(np.int16).ravel()
+    order = np.lexsort((move_idx, game))
+    x = rows[:, 28:28 + 96].copy().view(np.int16).reshape(n, 48)[order]
+    vis = rows[:, 28 + 96:28 + 96 + 128].copy().view(np.int32).reshape(n, 32)[order]
+    z = meta[:, 25].copy().view(np.int8)[order]
+    assert np.array_equal(x, got["x"]) and np.array_equal(vis, got["visits"]) and np.array_equal(z, got["z"])
+    assert np.array_equal(game[order], got["game_idx"]) and np.array_equal(move_idx[order], got["move_idx"])
+    e.close()

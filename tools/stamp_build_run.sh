@@ -1,0 +1,42 @@
+#!/bin/bash
+# Diagnostic: builds a STAMPED copy of the library (never the shipped one) and prints where a
+# k_tower wave spends its cycles.  Usage on the GPU box: bash tools/stamp_build_run.sh
+set -e
+cd "$(dirname "$0")/.."
+D=gpurun_out/stamp_build
+mkdir -p $D
+for f in tree engine nn; do
+  extra=""; [ $f = tree ] && extra="-ffp-contract=off"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DDBAZ_STAMP $extra -c dotsboxesaz_amd/csrc/$f.hip -o $D/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libdbaz_hip.so $D/tree.o $D/engine.o $D/nn.o
+python - <<'PY'
+import ctypes as C, numpy as np, torch, sys
+sys.path.insert(0, ".")
+from dotsboxesaz_amd import _lib
+_lib.LIB_PATH = "gpurun_out/stamp_build/libdbaz_hip.so"
+from dotsboxesaz_amd.engine import Engine
+from dotsboxesaz_amd import nn as dnn
+e = Engine(6, 6, 8192, evaluator="resnet", nn_precision=1)
+torch.manual_seed(0)
+m = dnn.ResNetZero(dnn.resnet_params(6, 6))
+e.load_state_dict(m.state_dict(), "resnet", **m.shape)
+X = np.random.RandomState(0).randint(0, 2, size=(8192, 3, 7, 7)).astype(np.float32)
+for _ in range(3):
+    e.predict(X)
+n_wg = 2048
+out = np.zeros((n_wg, 8, 5), np.uint64)
+L = _lib.load()
+L.dbaz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+rc = L.dbaz_debug_read_stamps(e.h, out.ctypes.data, n_wg)
+o = out.astype(np.float64)
+tot = o[..., 4]
+print("rc", rc, "waves", (tot > 0).sum())
+names = ["prologue(loads)", "main loop", "epilogue", "barrier wait", "layers total"]
+for i, nme in enumerate(names):
+    print("%-18s mean %10.0f cycles/wave   %5.1f %% of layers total" % (nme, o[..., i].mean(), 100 * o[..., i].mean() / tot.mean()))
+print("per layer: total %.0f, main %.0f (MFMA floor 7 tiles: %d, 6 tiles: %d)" % (tot.mean() / 40, o[..., 1].mean() / 40, 18 * 21 * 16, 18 * 18 * 16))
+for w in range(8):
+    print("wave", w, ["%.0f" % (o[:, w, i].mean() / 40) for i in range(5)])
+PY
