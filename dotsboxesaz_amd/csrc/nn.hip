@@ -4,20 +4,30 @@
 //   blocks x [conv3x3+BN+ReLU, conv3x3+BN, +x, ReLU] -> policy head (conv1x1+BN+ReLU,
 //   FC, softmax) / value head (conv1x1+BN+ReLU, FC, ReLU, FC, tanh); predict contract
 //   NeuralNetWrapper.predict_sync (nn.py:155-160): eval-mode BN, p = exp(log_softmax).
+// SimpleNN (reference dots_boxes_nn.py:61-98, 3x3 boards): BN follows the ReLU.
 //
-// Layout: activations NHWC float32 [sample][H*W][C]; eval-mode BatchNorms that FOLLOW a
-// conv are folded into its weights/bias on the host (double precision); bn_input is
-// applied to the in-bounds pixels when conv0 stages its input (zero padding happens after
-// bn_input in the reference, so it cannot be folded into conv0's bias).
+// Kernels
+//   k_tower<C,NTA,NTB,PREC>  the whole ResNetZero trunk in ONE launch: conv0, the 2*blocks
+//                            conv3x3 layers and both 1x1 head convs; the S samples of a
+//                            workgroup stay in two ping-pong LDS images, weights stream from L2
+//   k_simple_trunk<PREC>     the same for SimpleNN's conv0..conv4 (256 channels)
+//   k_dense                  SimpleNN's FC layers (f32 MFMA GEMM, 16 samples per workgroup)
+//   k_head_fc                head FCs + softmax / tanh (f32 MFMA GEMM, 16 samples per workgroup)
+// conv_lds_f32 / conv_lds_h3 are the per-layer device functions (LDS -> LDS).
 //
-// k_conv3x3 is the dominant kernel: an implicit GEMM  Out^T[cout][pos] = W[cout][tap,cin] *
-// In[tap,cin][pos]  on v_mfma_f32_16x16x4_f32 (exact f32: bitwise a k-ordered fmaf chain).
-// A operand = weights, pre-packed on the host in fragment order and streamed from L2
-// straight into registers (each wave owns one 16-cout tile, so no wave re-reads another
-// wave's weights); B operand = activations of S whole samples staged once in LDS
-// (row stride C+8 dwords => conflict-free ds_read_b128) and re-read for the 9 taps;
-// out-of-image taps read a shared zero row.  The accumulator layout puts 4 consecutive
-// couts of one position in each lane, so the epilogue (bias, residual, ReLU) is float4.
+// The conv layer is an implicit GEMM  Out^T[cout][pos] = W[cout][tap,cin] * In[tap,cin][pos].
+// A operand = weights, pre-packed on the host in fragment order and streamed from L2 straight
+// into registers (a wave owns one 16-cout tile and half of the 16-row position tiles);
+// B operand = activations read with ds_read_b128 (row stride C+8 dwords => conflict-free);
+// out-of-image taps read a zero region at the lane's own bank slot.  The accumulator layout
+// puts 4 consecutive couts of one position in each lane, so the epilogue (bias, residual,
+// ReLU) is vector code.  Eval-mode BatchNorms that FOLLOW a conv are folded into its
+// weights/bias on the host (double precision); bn_input is applied to the in-bounds pixels when
+// conv0 stages its input (zero padding happens after bn_input in the reference).
+//
+// PREC 0: exact f32 on v_mfma_f32_16x16x4_f32 (bitwise a k-ordered fmaf chain).
+// PREC 1: "f16x3" -- every f32 operand is an error-compensated (hi, lo) pair of halves on
+//         v_mfma_f32_16x16x32_f16 with f32 accumulation (see conv_lds_h3).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>

@@ -117,6 +117,8 @@ int dbaz_rules_features(dbaz_engine *e, int32_t n, const uint64_t *edges, const 
  * Weights arrive as state_dict entries under the reference's key names
  * ("resnet.resblocks.3.conv1.weight", ...), any order; dbaz_nn_commit folds the
  * eval-mode BatchNorms and uploads. */
+/* kind DBAZ_EVAL_RESNET: channels <= 128 (zero-padded to 16/32/64/128), blocks, head_channels, value_fc as in
+ * configuration.py:134-156.  kind DBAZ_EVAL_SIMPLENN: the other arguments are ignored; 3x3 boards only. */
 int dbaz_nn_configure(dbaz_engine *e, int32_t kind /*DBAZ_EVAL_RESNET|SIMPLENN*/, int32_t channels,
                       int32_t blocks, int32_t head_channels, int32_t value_fc);
 int dbaz_nn_set_tensor(dbaz_engine *e, const char *key, const float *data, int64_t numel);
