@@ -67,6 +67,13 @@ static int set_error(dbaz_engine *e, int code, const char *fmt, ...)
     return code;
 }
 
+// one handle = one GPU: every entry point re-selects the handle's device, so that a host that
+// switched the current HIP device in between (torch with several GPUs) cannot mis-route a launch
+#define USE_DEVICE(e)                                                                   \
+    do {                                                                                \
+        if (e) HIP_CHECK_RET(e, hipSetDevice((e)->cfg.device));                         \
+    } while (0)
+
 extern "C" const char *dbaz_last_error(const dbaz_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 extern "C" int dbaz_version(void) { return 1; }
 int nn_read_stamps(NNState *nn, unsigned long long *out, int n_wg);
@@ -133,6 +140,7 @@ static int upload_tables(dbaz_engine *e)
 extern "C" int dbaz_set_search_params(dbaz_engine *e, double cpuct, double cpuct_base, double noise_alpha, double noise_coeff)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (!(cpuct_base > 0)) return set_error(e, DBAZ_EINVAL, "cpuct_base must be > 0");
     const bool tables = cpuct != e->sc.cpuct || cpuct_base != e->sc.cpuct_base;
     e->sc.cpuct = cpuct; e->sc.cpuct_base = cpuct_base; e->sc.alpha = noise_alpha; e->sc.coeff = noise_coeff;
@@ -268,6 +276,7 @@ extern "C" void dbaz_destroy(dbaz_engine *e)
 extern "C" int dbaz_sync(dbaz_engine *e)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
     return DBAZ_OK;
 }
@@ -278,6 +287,7 @@ static int rules_call(dbaz_engine *e, int op, int32_t n, uint64_t *edges, int16_
                       int8_t *result, int16_t *x)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (n < 0) return set_error(e, DBAZ_EINVAL, "n < 0");
     if (n == 0) return DBAZ_OK;
     const Geo &g = e->g;
@@ -379,6 +389,7 @@ extern "C" int dbaz_nn_set_tensor(dbaz_engine *e, const char *key, const float *
 extern "C" int dbaz_nn_commit(dbaz_engine *e)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     std::string err;
     int r = nn_commit(e->nn, e->stream, err);
     if (r) return set_error(e, r, "%s", err.c_str());
@@ -388,6 +399,7 @@ extern "C" int dbaz_nn_commit(dbaz_engine *e)
 extern "C" int dbaz_nn_predict(dbaz_engine *e, int32_t n, const float *X, float *p, float *v)
 {
     if (!e || !X || !p || !v || n < 0) return e ? set_error(e, DBAZ_EINVAL, "bad argument") : DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (!nn_ready(e->nn)) return set_error(e, DBAZ_ESTATE, "network weights not committed (dbaz_nn_commit)");
     const Geo &g = e->g;
     const int F = 3 * g.HW;
@@ -438,6 +450,7 @@ static int check_slot_errors(dbaz_engine *e)
 extern "C" int dbaz_set_positions(dbaz_engine *e, const int16_t *moves, const int32_t *offsets)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     if ((moves == nullptr) != (offsets == nullptr)) return set_error(e, DBAZ_EINVAL, "moves and offsets must both be given");
     e->selfplay = false;
     e->search_open = false;
@@ -528,6 +541,7 @@ static int count_phases(dbaz_engine *e, int32_t out[4])
 extern "C" int dbaz_search_begin(dbaz_engine *e, const int32_t *num_reads, const double *noise)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (e->selfplay) return set_error(e, DBAZ_ESTATE, "self-play in progress; call dbaz_set_positions first");
     const int32_t *d_reads;
     int r = upload_search_inputs(e, num_reads, noise, &d_reads);
@@ -570,6 +584,7 @@ extern "C" int dbaz_search(dbaz_engine *e, const int32_t *num_reads, const doubl
 extern "C" int dbaz_select(dbaz_engine *e, int32_t *n_active, int16_t *leaf_x, uint8_t *need_eval)
 {
     if (!e || !n_active || !leaf_x || !need_eval) return e ? set_error(e, DBAZ_EINVAL, "null argument") : DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (!e->search_open) return set_error(e, DBAZ_ESTATE, "dbaz_search_begin not called");
     const Geo &g = e->g;
     const size_t F = 3 * g.HW, ns = e->n_slots;
@@ -597,6 +612,7 @@ extern "C" int dbaz_select(dbaz_engine *e, int32_t *n_active, int16_t *leaf_x, u
 extern "C" int dbaz_expand_backup(dbaz_engine *e, const float *p, const float *v)
 {
     if (!e || !p || !v) return e ? set_error(e, DBAZ_EINVAL, "null argument") : DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (!e->search_open) return set_error(e, DBAZ_ESTATE, "dbaz_search_begin not called");
     const Geo &g = e->g;
     std::vector<float> padded((size_t)e->n_slots * g.AS, 0.0f);
@@ -615,6 +631,7 @@ extern "C" int dbaz_get_roots(dbaz_engine *e, double *priors, float *total_value
                               int32_t *stats, float *q_value, float *root_tv, int32_t *root_nv)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     const Geo &g = e->g;
     const size_t ns = e->n_slots, A = g.A;
     int r = ensure_stage(e, Carver::need({ns * A * 8, ns * A * 4, ns * A * 4, ns * A * 4, ns * 12, ns * 4, ns * 4, ns * 4}));
@@ -648,6 +665,7 @@ extern "C" int dbaz_get_root_states(dbaz_engine *e, uint64_t *edges, int16_t *b2
                                     int8_t *just_played, int8_t *result, int8_t *expanded)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     const size_t ns = e->n_slots;
     int r = ensure_stage(e, Carver::need({ns * 32, ns * 4, ns, ns, ns, ns}));
     if (r) return r;
@@ -672,6 +690,7 @@ extern "C" int dbaz_get_root_states(dbaz_engine *e, uint64_t *edges, int16_t *b2
 extern "C" int dbaz_advance(dbaz_engine *e, const int32_t *moves, int32_t reuse_tree)
 {
     if (!e || !moves) return e ? set_error(e, DBAZ_EINVAL, "null argument") : DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (e->selfplay) return set_error(e, DBAZ_ESTATE, "self-play in progress");
     int r = ensure_stage(e, Carver::need({(size_t)e->n_slots * 4}));
     if (r) return r;
@@ -722,6 +741,7 @@ extern "C" int dbaz_selfplay_fastforward(dbaz_engine *e, const int32_t *plies)
 extern "C" int dbaz_selfplay_start(dbaz_engine *e, int64_t n_games, int64_t first_game_idx)
 {
     if (!e || n_games < 0) return e ? set_error(e, DBAZ_EINVAL, "bad argument") : DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (e->sc.evaluator == DBAZ_EVAL_EXTERNAL) return set_error(e, DBAZ_ESTATE, "self-play needs a device evaluator");
     if ((e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN) && !nn_ready(e->nn))
         return set_error(e, DBAZ_ESTATE, "network weights not committed (dbaz_nn_commit)");
@@ -772,6 +792,7 @@ extern "C" int dbaz_selfplay_start(dbaz_engine *e, int64_t n_games, int64_t firs
 extern "C" int dbaz_step(dbaz_engine *e, int32_t k)
 {
     if (!e || k < 0) return e ? set_error(e, DBAZ_EINVAL, "bad argument") : DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (!e->selfplay) return set_error(e, DBAZ_ESTATE, "dbaz_selfplay_start not called");
     for (int i = 0; i < k; i++) {
         int r = sim_step(e, true);
@@ -803,6 +824,7 @@ static int slot_summary(dbaz_engine *e, dbaz_counters *c)
 extern "C" int dbaz_get_counters(dbaz_engine *e, dbaz_counters *out)
 {
     if (!e || !out) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
     memset(out, 0, sizeof(*out));
     int r = slot_summary(e, out);
@@ -857,6 +879,7 @@ extern "C" int dbaz_run(dbaz_engine *e, int64_t max_steps)
 extern "C" int dbaz_timing_begin(dbaz_engine *e)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
     e->timing = true;
     e->ev_used = 0;
@@ -870,6 +893,7 @@ extern "C" int dbaz_timing_begin(dbaz_engine *e)
 extern "C" int dbaz_timing_end(dbaz_engine *e)
 {
     if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
     if (!e->timing) return set_error(e, DBAZ_ESTATE, "dbaz_timing_begin not called");
     HIP_CHECK_RET(e, hipEventRecord(e->ev_t1, e->stream));
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
@@ -893,6 +917,7 @@ extern "C" int dbaz_fetch_samples(dbaz_engine *e, int32_t max_rows, int32_t *n_r
                                   int16_t *played)
 {
     if (!e || !n_rows) return e ? set_error(e, DBAZ_EINVAL, "null argument") : DBAZ_EINVAL;
+    USE_DEVICE(e);
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
     const Geo &g = e->g;
     const int F = 3 * g.HW, A = g.A;
@@ -952,6 +977,7 @@ extern "C" int dbaz_debug_read_stamps(dbaz_engine *e, unsigned long long *out, i
 
 extern "C" int dbaz_replay_rows_dev(dbaz_engine *e, void **rows_dev, int32_t *n_rows, int32_t *row_bytes)
 {
+    USE_DEVICE(e);
     // replay row (fixed stride): RowMeta (24 B) | x int16[3HW] | visits int32[A], padded to 8 B
     if (!e || !rows_dev || !n_rows || !row_bytes) return e ? set_error(e, DBAZ_EINVAL, "null argument") : DBAZ_EINVAL;
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
