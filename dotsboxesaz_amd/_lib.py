@@ -18,7 +18,7 @@ EVAL_FORMULA_HASH, EVAL_FORMULA_UNIFORM, EVAL_RESNET, EVAL_SIMPLENN, EVAL_EXTERN
 SYMBOLS = [
     "dbaz_last_error", "dbaz_version", "dbaz_create", "dbaz_destroy", "dbaz_sync",
     "dbaz_rules_init", "dbaz_rules_valid_moves", "dbaz_rules_play", "dbaz_rules_result", "dbaz_rules_features",
-    "dbaz_nn_configure", "dbaz_nn_set_tensor", "dbaz_nn_commit", "dbaz_nn_predict",
+    "dbaz_nn_configure", "dbaz_nn_select_model", "dbaz_nn_set_tensor", "dbaz_nn_commit", "dbaz_nn_predict",
     "dbaz_set_search_params", "dbaz_set_positions", "dbaz_search", "dbaz_search_begin", "dbaz_select", "dbaz_expand_backup",
     "dbaz_get_roots", "dbaz_get_root_states", "dbaz_advance",
     "dbaz_selfplay_start", "dbaz_selfplay_script", "dbaz_selfplay_fastforward", "dbaz_step", "dbaz_run",
@@ -33,7 +33,7 @@ class Config(C.Structure):
         ("noise_alpha", C.c_double), ("noise_coeff", C.c_double), ("reuse_tree", C.c_int32),
         ("n_temp", C.c_int32), ("temp_idx", C.c_int32 * 8), ("temp_val", C.c_double * 8),
         ("evaluator", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64), ("max_out_rows", C.c_int32),
-        ("nn_precision", C.c_int32),
+        ("nn_precision", C.c_int32), ("match_play", C.c_int32), ("evaluator2", C.c_int32),
     ]
 
 
@@ -79,6 +79,7 @@ def load():
     L.dbaz_rules_result.argtypes = [vp, i32, vp, vp, vp]
     L.dbaz_rules_features.argtypes = [vp, i32, vp, vp, vp, vp]
     L.dbaz_nn_configure.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.dbaz_nn_select_model.argtypes = [vp, i32]
     L.dbaz_nn_set_tensor.argtypes = [vp, C.c_char_p, vp, i64]
     L.dbaz_nn_commit.argtypes = [vp]
     L.dbaz_nn_predict.argtypes = [vp, i32, vp, vp, vp]

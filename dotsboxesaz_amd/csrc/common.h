@@ -61,7 +61,7 @@ struct Slot {
     int32_t pool_high;
     int64_t n_search, sum_path, n_eval, n_term;
     int32_t ff_plies;        // pending fast-forward plies (benchmark population)
-    int32_t pad;
+    int32_t model;           // match play: which of the two evaluators serves this slot's current search
 };
 
 struct PathEnt {
@@ -87,6 +87,8 @@ struct SearchCfg {
     int temp_idx[8];
     double temp_val[8];
     int evaluator;
+    int match_play;          // two-model match play (self_play.compute_elo): evaluator by root to_play
+    int evaluator2;          // evaluator of model 1
     uint64_t seed;
     int table_n;             // entries in pbc/sqrt tables
 };
@@ -102,8 +104,9 @@ struct TreeBufs {
     float *feat;       // [n_slots][3*HW] leaf features (float32 planes, predict_sync layout)
     float *evalP;      // [n_slots][AS]
     float *evalV;      // [n_slots]
-    int32_t *eval_list;// [n_slots] compacted slots needing an NN evaluation
-    int32_t *n_eval;   // [1]
+    int32_t *eval_list;// [n_slots] compacted slots needing an NN evaluation (model 0)
+    int32_t *eval_list2;// [n_slots] same for model 1 (match play)
+    int32_t *n_eval;   // [2] list lengths
     int32_t *remap;    // [n_slots][cap] compaction scratch
     const double *pbc_table;  // log((N+base+1)/base)+cpuct for N < table_n (host libm)
     const double *sqrt_table; // sqrt(N)

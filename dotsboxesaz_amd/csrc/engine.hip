@@ -27,7 +27,9 @@ struct dbaz_engine {
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void *> allocs;
-    NNState *nn = nullptr;
+    NNState *nn = nullptr;   // the model that dbaz_nn_* calls address (nns[cur_model])
+    NNState *nns[2] = {nullptr, nullptr};
+    int cur_model = 0;
     // staging (device) for the boundary
     void *stage = nullptr;
     size_t stage_bytes = 0;
@@ -156,6 +158,8 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     if (cfg->n_slots < 1) return set_error(nullptr, DBAZ_EINVAL, "n_slots must be >= 1");
     if (cfg->mcts_num_read < 0 || cfg->cpuct_base <= 0) return set_error(nullptr, DBAZ_EINVAL, "bad search parameters");
     if (cfg->evaluator < 0 || cfg->evaluator > DBAZ_EVAL_EXTERNAL) return set_error(nullptr, DBAZ_EINVAL, "bad evaluator");
+    if (cfg->match_play && (cfg->evaluator2 < 0 || cfg->evaluator2 >= DBAZ_EVAL_EXTERNAL || cfg->evaluator == DBAZ_EVAL_EXTERNAL))
+        return set_error(nullptr, DBAZ_EINVAL, "match play needs two device evaluators");
     if (cfg->n_temp < 0 || cfg->n_temp > 8) return set_error(nullptr, DBAZ_EINVAL, "n_temp must be in 0..8");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
@@ -203,6 +207,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     sc.mcts_num_read = cfg->mcts_num_read; sc.reuse_tree = cfg->reuse_tree; sc.n_temp = cfg->n_temp;
     for (int i = 0; i < cfg->n_temp; i++) { sc.temp_idx[i] = cfg->temp_idx[i]; sc.temp_val[i] = cfg->temp_val[i]; }
     sc.evaluator = cfg->evaluator; sc.seed = cfg->seed;
+    sc.match_play = cfg->match_play ? 1 : 0; sc.evaluator2 = cfg->evaluator2;
 
     TreeBufs &B = e->B;
     memset(&B, 0, sizeof(B));
@@ -220,6 +225,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     CREATE_CHECK(dmalloc(e, &B.evalP, ns * g.AS));
     CREATE_CHECK(dmalloc(e, &B.evalV, ns));
     CREATE_CHECK(dmalloc(e, &B.eval_list, ns));
+    CREATE_CHECK(dmalloc(e, &B.eval_list2, ns));
     CREATE_CHECK(dmalloc(e, &B.n_eval, 4));
     CREATE_CHECK(dmalloc(e, &B.remap, ns * g.cap, false));
     CREATE_CHECK(dmalloc(e, &B.row_x, ns * rcap * F, false));
@@ -249,7 +255,9 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     }
     B.first_game = 0;
     B.last_game = 0;
-    e->nn = nn_create(g, e->n_slots, cfg->nn_precision);
+    e->nns[0] = nn_create(g, e->n_slots, cfg->nn_precision);
+    e->nns[1] = nn_create(g, e->n_slots, cfg->nn_precision);
+    e->nn = e->nns[0];
     CREATE_HIP(hipStreamSynchronize(e->stream));
     // every slot starts as an idle empty board
     tree_launch_set_positions(e->stream, g, sc, B, e->n_slots, nullptr, nullptr);
@@ -262,7 +270,7 @@ extern "C" void dbaz_destroy(dbaz_engine *e)
 {
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->nn) nn_destroy(e->nn);
+    for (int i = 0; i < 2; i++) if (e->nns[i]) nn_destroy(e->nns[i]);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stage) (void)hipFree(e->stage);
     if (e->replay_dev) (void)hipFree(e->replay_dev);
@@ -378,6 +386,15 @@ extern "C" int dbaz_nn_configure(dbaz_engine *e, int32_t kind, int32_t channels,
     if (r) return set_error(e, r, "%s", err.c_str());
     return DBAZ_OK;
 }
+extern "C" int dbaz_nn_select_model(dbaz_engine *e, int32_t model)
+{
+    if (!e) return DBAZ_EINVAL;
+    if (model < 0 || model > 1) return set_error(e, DBAZ_EINVAL, "model must be 0 or 1");
+    e->cur_model = model;
+    e->nn = e->nns[model];
+    return DBAZ_OK;
+}
+
 extern "C" int dbaz_nn_set_tensor(dbaz_engine *e, const char *key, const float *data, int64_t numel)
 {
     if (!e || !key || !data) return e ? set_error(e, DBAZ_EINVAL, "null argument") : DBAZ_EINVAL;
@@ -487,13 +504,19 @@ static hipEvent_t next_event(dbaz_engine *e)
 static int sim_step(dbaz_engine *e, bool with_driver)
 {
     hipStream_t s = e->stream;
-    const bool use_nn = e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN;
-    if (use_nn) HIP_CHECK_RET(e, hipMemsetAsync(e->B.n_eval, 0, 4, s));
+    auto is_nn = [](int ev) { return ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN; };
+    const bool use_nn = is_nn(e->sc.evaluator);
+    const bool use_nn2 = e->sc.match_play && is_nn(e->sc.evaluator2);
+    if (use_nn || use_nn2) HIP_CHECK_RET(e, hipMemsetAsync(e->B.n_eval, 0, 8, s));
     tree_launch_select(s, e->g, e->sc, e->B, e->n_slots);
     if (use_nn) {
         hipEvent_t a = nullptr, b = nullptr;
         if (e->timing) { a = next_event(e); b = next_event(e); }
-        nn_forward(e->nn, s, e->B.feat, e->B.eval_list, e->B.n_eval, e->n_slots, e->B.evalP, e->B.evalV, e->g.AS, a, b);
+        nn_forward(e->nns[0], s, e->B.feat, e->B.eval_list, e->B.n_eval, e->n_slots, e->B.evalP, e->B.evalV, e->g.AS, a, b);
+        e->nn_launches++;
+    }
+    if (use_nn2) {
+        nn_forward(e->nns[1], s, e->B.feat, e->B.eval_list2, e->B.n_eval + 1, e->n_slots, e->B.evalP, e->B.evalV, e->g.AS, nullptr, nullptr);
         e->nn_launches++;
     }
     tree_launch_expand_backup(s, e->g, e->sc, e->B, e->n_slots);
@@ -561,7 +584,7 @@ extern "C" int dbaz_search(dbaz_engine *e, const int32_t *num_reads, const doubl
     if (!e) return DBAZ_EINVAL;
     if (e->sc.evaluator == DBAZ_EVAL_EXTERNAL)
         return set_error(e, DBAZ_ESTATE, "external evaluator: use dbaz_search_begin/dbaz_select/dbaz_expand_backup");
-    if ((e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN) && !nn_ready(e->nn))
+    if ((e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN) && !nn_ready(e->nns[0]))
         return set_error(e, DBAZ_ESTATE, "network weights not committed (dbaz_nn_commit)");
     int r = dbaz_search_begin(e, num_reads, noise);
     if (r) return r;
@@ -743,8 +766,10 @@ extern "C" int dbaz_selfplay_start(dbaz_engine *e, int64_t n_games, int64_t firs
     if (!e || n_games < 0) return e ? set_error(e, DBAZ_EINVAL, "bad argument") : DBAZ_EINVAL;
     USE_DEVICE(e);
     if (e->sc.evaluator == DBAZ_EVAL_EXTERNAL) return set_error(e, DBAZ_ESTATE, "self-play needs a device evaluator");
-    if ((e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN) && !nn_ready(e->nn))
+    if ((e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN) && !nn_ready(e->nns[0]))
         return set_error(e, DBAZ_ESTATE, "network weights not committed (dbaz_nn_commit)");
+    if (e->sc.match_play && (e->sc.evaluator2 == DBAZ_EVAL_RESNET || e->sc.evaluator2 == DBAZ_EVAL_SIMPLENN) && !nn_ready(e->nns[1]))
+        return set_error(e, DBAZ_ESTATE, "network weights of model 1 not committed (dbaz_nn_select_model(1), dbaz_nn_commit)");
     TreeBufs &B = e->B;
     hipStream_t s = e->stream;
     HIP_CHECK_RET(e, hipStreamSynchronize(s));
@@ -843,7 +868,7 @@ extern "C" int dbaz_get_counters(dbaz_engine *e, dbaz_counters *out)
     out->ms_nn_tower = e->ms_nn_tower;
     out->ms_tree = e->ms_total - e->ms_nn_tower;
     out->nn_launches = e->nn_launches;
-    if (nn_overflowed(e->nn))
+    if (nn_overflowed(e->nns[0]) || nn_overflowed(e->nns[1]))
         return set_error(e, DBAZ_EDEVICE, "nn_precision=1: an activation left the f16 range; use nn_precision=0 for this network");
     return DBAZ_OK;
 }

@@ -376,6 +376,9 @@ __global__ void __launch_bounds__(WAVE) k_select(Geo g, SearchCfg cfg, TreeBufs 
     int Nself = S->root_N;
     NodeMeta m = load_meta(pool, g, 0);
     in_move = m.move;
+    // match play (self_play.py:59,237-239): the player to move at the ROOT selects the model for the
+    // whole search of this move; odd games swap the seats (the reference shuffles them by worker pid)
+    const int model = cfg.match_play ? ((m.st.to_play ^ (int)(S->game_idx & 1)) & 1) : 0;
     if ((m.flags & NF_EXPANDED) && !(m.flags & NF_TERMINAL)) {
         if (lane == 0)
             S->root_W = S->root_W - 1.0f; // current.total_value -= VIRTUAL_LOSS (root slot)
@@ -481,6 +484,7 @@ __global__ void __launch_bounds__(WAVE) k_select(Geo g, SearchCfg cfg, TreeBufs 
         S->leaf_result = m.result;
         S->leaf_to_play = m.st.to_play;
         S->n_nodes = n_nodes;
+        S->model = model;
         if (n_nodes > S->pool_high) S->pool_high = n_nodes;
     }
     if (!(m.flags & NF_TERMINAL)) {
@@ -488,9 +492,10 @@ __global__ void __launch_bounds__(WAVE) k_select(Geo g, SearchCfg cfg, TreeBufs 
         float *f = B.feat + (size_t)slot * 3 * g.HW;
         for (int i = lane; i < 3 * g.HW; i += WAVE)
             f[i] = (float)gs_feature(g, m.st, i);
-        if (lane == 0 && (cfg.evaluator == DBAZ_EVAL_RESNET || cfg.evaluator == DBAZ_EVAL_SIMPLENN)) {
-            int j = atomicAdd(B.n_eval, 1);
-            B.eval_list[j] = slot;
+        const int ev = model ? cfg.evaluator2 : cfg.evaluator;
+        if (lane == 0 && (ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN)) {
+            int j = atomicAdd(B.n_eval + model, 1);
+            (model ? B.eval_list2 : B.eval_list)[j] = slot;
         }
     }
 }
@@ -517,11 +522,12 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
     if (!(lm.flags & NF_TERMINAL)) {
         float *Prow = reinterpret_cast<float *>(nd + META_DW);
         uint64_t h = 0;
-        const bool formula = cfg.evaluator == DBAZ_EVAL_FORMULA_HASH || cfg.evaluator == DBAZ_EVAL_FORMULA_UNIFORM;
+        const int ev = (cfg.match_play && S->model) ? cfg.evaluator2 : cfg.evaluator;
+        const bool formula = ev == DBAZ_EVAL_FORMULA_HASH || ev == DBAZ_EVAL_FORMULA_UNIFORM;
         if (formula) h = formula_hash(lm.st);
         const float *ep = B.evalP + (size_t)slot * g.AS;
         for (int i = lane; i < A; i += WAVE) {
-            float p = formula ? formula_p(h, i, cfg.evaluator) : ep[i];
+            float p = formula ? formula_p(h, i, ev) : ep[i];
             ldsf[i] = p * (gs_valid(g, lm.st, i) ? 1.0f : 0.0f); // child_priors * valid
         }
         __syncthreads();
@@ -529,7 +535,7 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
         const bool renorm = (s > 0.0f) && (s != 1.0f);
         for (int i = lane; i < A; i += WAVE)
             Prow[i] = renorm ? ldsf[i] / s : ldsf[i];
-        v = formula ? formula_v(h, cfg.evaluator) : B.evalV[slot];
+        v = formula ? formula_v(h, ev) : B.evalV[slot];
     } else {
         v = (float)lm.result; // get_result(), python int
     }

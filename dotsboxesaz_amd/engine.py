@@ -30,7 +30,7 @@ class Engine:
 
     def __init__(self, rows, cols, n_slots, mcts_num_read=800, cpuct=(1.25, 19652), noise=(0.0, 0.0),
                  temperature=None, reuse_tree=True, evaluator="formula", nodes_per_slot=0, seed=0, device=0,
-                 max_out_rows=0, nn_precision=0):
+                 max_out_rows=0, nn_precision=0, match_play=False, evaluator2="formula"):
         self._L = _lib.load()
         self.rows, self.cols = int(rows), int(cols)
         self.H, self.W = self.rows + 1, self.cols + 1
@@ -51,6 +51,8 @@ class Engine:
         cfg.evaluator = self.EVALUATORS[evaluator] if isinstance(evaluator, str) else int(evaluator)
         cfg.device, cfg.seed, cfg.max_out_rows = int(device), int(seed), int(max_out_rows)
         cfg.nn_precision = int(nn_precision)
+        cfg.match_play = int(bool(match_play))
+        cfg.evaluator2 = self.EVALUATORS[evaluator2] if isinstance(evaluator2, str) else int(evaluator2)
         self.cfg = cfg
         self._drained = []
         self.h = C.c_void_p()
@@ -122,8 +124,16 @@ class Engine:
         return out
 
     # ---------------------------------------------------------------- network (N1-N3)
-    def load_state_dict(self, state_dict, kind="resnet", channels=64, blocks=20, head_channels=16, value_fc=8):
-        """state_dict: mapping of the reference's key names to arrays (torch tensors or numpy)."""
+    def load_state_dict(self, state_dict, kind="resnet", channels=64, blocks=20, head_channels=16, value_fc=8, model=0):
+        """state_dict: mapping of the reference's key names to arrays (torch tensors or numpy).
+        model: 0 or 1 (the two players of match play)."""
+        self._ck(self._L.dbaz_nn_select_model(self.h, int(model)))
+        try:
+            self._load_state_dict(state_dict, kind, channels, blocks, head_channels, value_fc)
+        finally:
+            self._L.dbaz_nn_select_model(self.h, 0)
+
+    def _load_state_dict(self, state_dict, kind, channels, blocks, head_channels, value_fc):
         self._ck(self._L.dbaz_nn_configure(self.h, self.EVALUATORS[kind], channels, blocks, head_channels, value_fc))
         for k, v in state_dict.items():
             if k.endswith("num_batches_tracked"):

@@ -184,3 +184,75 @@ def gather_replay(engine, dist, synthetic_rows=0):
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0)
     return int(sum(counts)), ms
+
+
+# ---------------------------------------------------------------------------------------
+# two-model match play + Elo (self_play.compute_elo, self_play.py:309-344)
+# ---------------------------------------------------------------------------------------
+def elo_rating2(elo0, elo1, n0, n1, K=30):
+    """utils/utils.py:124-132."""
+    import math
+    p1 = 1.0 / (1 + 1.0 * math.pow(10, (elo0 - elo1) / 400))
+    p0 = 1 - p1
+    return elo0 + K * (n0 * p1 - n1 * p0), elo1 + K * (n1 * p0 - n0 * p1)
+
+
+def match_winners(samples, generations):
+    """(n0, n1): wins of generations[0] / generations[1] counted as the reference does
+    (self_play.py:336-338): per game the first row (lowest move_idx) with z == 1 names the winner;
+    drawn games have no such row.  Seats: model = player XOR (game_idx & 1)."""
+    gen = np.where((samples["player"] ^ (samples["game_idx"] & 1)) == 0, generations[0], generations[1])
+    n0 = n1 = 0
+    for g in np.unique(samples["game_idx"]):
+        r = np.nonzero((samples["game_idx"] == g) & (samples["z"] == 1))[0]
+        if len(r) == 0:
+            continue
+        first = r[np.argmin(samples["move_idx"][r])]
+        if gen[first] == generations[0]:
+            n0 += 1
+        else:
+            n1 += 1
+    return n0, n1
+
+
+def compute_elo(elo_params, params, generations, elos, nn_classes=None, rows=None, cols=None, n_slots=None, device=0):
+    """Reference: self_play.compute_elo(elo_params, [params0, params1], [gen0, gen1], (elo0, elo1)).
+    The two models play elo_params.n_games games against each other on the GPU: the model of the
+    player to move at the root runs that move's whole search (self_play.py:59,237-239), seats are
+    swapped on odd games, the `self_play_override` of elo_params applies (no tree reuse, no noise,
+    1200 reads in the shipped configuration, configuration.py:107-113).
+    Returns (elo0, elo1, n1 / number of decided games)."""
+    from .engine import Engine
+    p0, p1 = params
+    over = _get(elo_params, "self_play_override", {}) or {}
+    kw = engine_kwargs_from_params(p0)
+    if "reuse_mcts_tree" in over:
+        kw["reuse_tree"] = bool(_get(over, "reuse_mcts_tree"))
+    if "noise" in over:
+        nz = _get(over, "noise")
+        kw["noise"] = (float(nz[0]), float(nz[1]))
+    m = _get(over, "mcts")
+    if m is not None and _get(m, "mcts_num_read") is not None:
+        kw["mcts_num_read"] = int(_get(m, "mcts_num_read"))
+    if rows is None:
+        game = _get(p0, "game")
+        dims = _get(game, "dims") or getattr(_get(game, "clazz"), "BOARD_DIM", (3, 3))
+        rows, cols = int(dims[0]), int(dims[1])
+    n_games = int(_get(elo_params, "n_games"))
+    classes = nn_classes or [_get(_get(p, "nn"), "model_class") for p in params]
+    models = [classes[0](p0), classes[1](p1)]
+    for mdl, gen in zip(models, generations):
+        if gen != 0:
+            mdl.load_parameters(gen)  # compare_models: generation g itself (self_play.py:190)
+    eng = Engine(rows, cols, n_slots or max(1, min(n_games, 4096)), evaluator=models[0].kind, evaluator2=models[1].kind,
+                 match_play=True, device=device, **kw)
+    for i, mdl in enumerate(models):
+        eng.load_state_dict(mdl.state_dict(), mdl.kind, model=i, **mdl.shape)
+    eng.selfplay_start(n_games, 0)
+    eng.run()
+    got = eng.fetch_samples()
+    eng.close()
+    n0, n1 = match_winners(got, generations)
+    e0, e1 = elo_rating2(elos[0], elos[1], n0, n1, K=30)
+    decided = n0 + n1
+    return e0, e1, (n1 / decided if decided else float("nan"))

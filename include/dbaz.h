@@ -67,6 +67,9 @@ typedef struct {
     uint64_t seed;          /* Philox key for move sampling / Dirichlet noise */
     int32_t max_out_rows;   /* capacity of the finished-sample buffer; 0 = max(4096, 2*n_slots*(E+1)) */
     int32_t nn_precision;   /* 0 = exact f32 MFMA; 1 = f16x3 split MFMA (f32-grade) */
+    int32_t match_play;     /* two-model match play (self_play.compute_elo, :309-344): the evaluator of a move's
+                               search is model (root.to_play XOR game_idx&1) */
+    int32_t evaluator2;     /* DBAZ_EVAL_* of model 1 (match play) */
 } dbaz_config;
 
 typedef struct {
@@ -121,6 +124,8 @@ int dbaz_rules_features(dbaz_engine *e, int32_t n, const uint64_t *edges, const 
  * configuration.py:134-156.  kind DBAZ_EVAL_SIMPLENN: the other arguments are ignored; 3x3 boards only. */
 int dbaz_nn_configure(dbaz_engine *e, int32_t kind /*DBAZ_EVAL_RESNET|SIMPLENN*/, int32_t channels,
                       int32_t blocks, int32_t head_channels, int32_t value_fc);
+/* match play: subsequent dbaz_nn_configure/_set_tensor/_commit/_predict address model 0 or 1 */
+int dbaz_nn_select_model(dbaz_engine *e, int32_t model);
 int dbaz_nn_set_tensor(dbaz_engine *e, const char *key, const float *data, int64_t numel);
 int dbaz_nn_commit(dbaz_engine *e);
 /* NeuralNetWrapper.predict_sync: X float32 [n,3,H,W] -> softmax p [n,A], tanh v [n] */

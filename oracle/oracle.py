@@ -70,6 +70,7 @@ class Game(C.Structure):
 EVAL_FN = C.CFUNCTYPE(None, C.POINTER(Dims), C.POINTER(State), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
 CHOICE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
 NOISE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_void_p)
+MOVE_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
 
 _lib = None
 
@@ -110,7 +111,7 @@ def lib():
         L.ob_tree_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ob_play_game.argtypes = [C.POINTER(Dims), C.POINTER(State), C.POINTER(SelfPlayParams),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_int]
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ob_play_game.restype = C.POINTER(Game)
         L.ob_game_free.argtypes = [C.POINTER(Game)]
         L.ob_choice_xorshift.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -300,7 +301,7 @@ def selfplay_params(mcts_num_read=800, cpuct=(1.25, 19652), noise=(0.8, 0.25), r
     return pp
 
 
-def play_game(d, pp, evaluator, start=None, choice=None, noise=None, forced_moves=None, rng_state=None):
+def play_game(d, pp, evaluator, start=None, choice=None, noise=None, forced_moves=None, rng_state=None, on_move=None):
     """SelfPlay.play_game + its rows of get_datasets.
 
     choice(probs)->move and noise(A, alpha)->f64[A] are python callables (pass
@@ -333,8 +334,13 @@ def play_game(d, pp, evaluator, start=None, choice=None, noise=None, forced_move
     if forced_moves is not None:
         fm = np.ascontiguousarray(forced_moves, dtype=np.int16)
         nf = fm.size
+    mv_ptr = None
+    if on_move is not None:
+        cb3 = MOVE_FN(lambda tp, _u: on_move(int(tp)))
+        keep.append(cb3)
+        mv_ptr = C.cast(cb3, C.c_void_p)
     gp = L.ob_play_game(C.byref(d), C.byref(start), C.byref(pp), evaluator.fn_ptr, evaluator.user,
-                        ch_ptr, ch_user, nz_ptr, nz_user, fm.ctypes.data if fm is not None else None, nf)
+                        ch_ptr, ch_user, nz_ptr, nz_user, fm.ctypes.data if fm is not None else None, nf, mv_ptr, None)
     g = gp.contents
     n, A, F = g.n_rows, d.A, 3 * d.H * d.W
 

@@ -464,9 +464,71 @@ def gen_selfplay():
     print("selfplay.npz", len(cases), "cases")
 
 
+# ---------------------------------------------------------------- match play / Elo
+def gen_match():
+    """self_play.compute_elo's game loop: SelfPlay with a player_change_callback that swaps the
+    evaluator by root.to_play (self_play.py:59,237-239), no tree reuse, no noise, rows without
+    features (get_datasets(generations, with_features=False)), and utils.elo_rating2."""
+    import self_play as ref_sp
+    from utils.utils import DotDict, elo_rating2
+    out = {}
+    cases = []
+    for (name, rows, cols, sims, n_games, seed) in (("m33", 3, 3, 30, 4, 5), ("m23", 2, 3, 40, 3, 6)):
+        set_board(rows, cols)
+        params = DotDict({"self_play": {"reuse_mcts_tree": False, "noise": [0.0, 0.0],
+                                        "mcts": {"mcts_num_read": sims, "mcts_cpuct": [1.25, 19652],
+                                                 "temperature": {0: 1.0, 12: 0.02}, "max_async_searches": 1}}})
+        np.random.seed(seed)
+        state = {"model": 0, "game": 0}
+
+        async def nn(st, _s=state):
+            return formula_eval(st, 0 if _s["model"] == 0 else 1)  # model 0: hash formula, model 1: uniform
+
+        drawn = []
+        o_ch = np.random.choice
+
+        def rec_choice(a, size=None, replace=True, p=None):
+            r = o_ch(a, size, replace, p)
+            drawn.append(int(np.asarray(r).ravel()[0]))
+            return r
+
+        np.random.choice = rec_choice
+        try:
+            sp = ref_sp.SelfPlay(nn, params)
+            # seats are swapped on odd games (the reference swaps them by worker pid, self_play.py:202-209)
+            sp.set_player_change_callback(lambda player, _s=state: _s.__setitem__("model", player ^ (_s["game"] & 1)))
+            for gi in range(n_games):
+                state["game"] = gi
+                run(sp.play_game(BoxesState(), gi))
+        finally:
+            np.random.choice = o_ch
+        df = sp.get_datasets([7, 9], with_features=False).reset_index()
+        assert not any(c.startswith("x_") for c in df.columns)
+        A = 2 * (rows + 1) * (cols + 1)
+        k = name + "_"
+        out[k + "cfg"] = np.array([rows, cols, sims, n_games, seed], dtype=np.int32)
+        out[k + "index"] = df[["generation", "game_idx", "move_idx"]].to_numpy().astype(np.int16)
+        out[k + "move"] = df["move"].to_numpy().astype(np.int16)
+        out[k + "player"] = df["player"].to_numpy().astype(np.int8)
+        out[k + "pi"] = df[["pi_%d" % i for i in range(A)]].to_numpy().astype(np.float64)
+        out[k + "z"] = df["z"].to_numpy().astype(np.int64)
+        out[k + "stats"] = df[["max_deepness", "tree_size", "terminal_count"]].to_numpy().astype(np.int32)
+        out[k + "q"] = df["q_value"].to_numpy().astype(np.float32)
+        out[k + "drawn_moves"] = np.array(drawn, dtype=np.int16)
+        out[k + "columns"] = np.array(list(df.columns))
+        cases.append(name)
+        print("  ", name, "rows", len(df))
+    tuples = [(1000.0, 1000.0, 12, 8), (1200.0, 950.5, 3, 17), (0.0, 0.0, 0, 20), (1500.0, 1500.0, 10, 10), (-30.5, 400.0, 7, 0)]
+    out["elo_in"] = np.array(tuples, dtype=np.float64)
+    out["elo_out"] = np.array([elo_rating2(a, b, int(n0), int(n1), K=30) for (a, b, n0, n1) in tuples], dtype=np.float64)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "match.npz"), **out)
+    print("match.npz", len(cases), "cases")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="rules,boards,mcts,nn,selfplay")
+    ap.add_argument("--only", default="rules,boards,mcts,nn,selfplay,match")
     args = ap.parse_args()
     todo = args.only.split(",")
     if "rules" in todo:
@@ -479,3 +541,5 @@ if __name__ == "__main__":
         gen_nn()
     if "selfplay" in todo:
         gen_selfplay()
+    if "match" in todo:
+        gen_match()

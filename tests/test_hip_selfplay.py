@@ -192,3 +192,65 @@ def test_replay_rows_stay_in_hbm_and_match_fetch():
     assert np.array_equal(x, got["x"]) and np.array_equal(vis, got["visits"]) and np.array_equal(z, got["z"])
     assert np.array_equal(game[order], got["game_idx"]) and np.array_equal(move_idx[order], got["move_idx"])
     e.close()
+
+
+# ---------------------------------------------------------------- match play
+@pytest.mark.parametrize("n_slots", [1, 8])
+def test_match_play_golden(n_slots):
+    """Two evaluators in one engine (model 0 = hash formula, model 1 = uniform), the model of the
+    player to move at the root serves the move's search, seats swapped on odd games; rows equal the
+    reference's compute_elo game loop bit for bit (teacher-forced moves)."""
+    from dotsboxesaz_amd.engine import Engine
+    from dotsboxesaz_amd.self_play import match_winners
+    from test_oracle_selfplay import match_games
+    g = load_golden("match.npz")
+    for name in [str(c) for c in g["cases"]]:
+        rows, cols, sims, n_games, _seed = [int(x) for x in g[name + "_cfg"]]
+        e = Engine(rows, cols, n_slots, mcts_num_read=sims, noise=(0.0, 0.0), reuse_tree=False, evaluator="formula",
+                   evaluator2="uniform", match_play=True)
+        games = match_games(g, name)
+        for gi, gg in enumerate(games):
+            e.selfplay_script(gi, gg["moves"])
+        e.selfplay_start(n_games, 0)
+        e.run()
+        got = e.fetch_samples()
+        r = np.concatenate([gg["rows"] for gg in games])
+        assert np.array_equal(got["played"], np.concatenate([gg["moves"] for gg in games]))
+        assert np.array_equal(got["move"], g[name + "_move"][r])
+        assert np.array_equal(got["player"], g[name + "_player"][r])
+        assert np.array_equal(got["pi"].view(np.uint64), g[name + "_pi"][r].view(np.uint64))
+        assert np.array_equal(got["z"].astype(np.int64), g[name + "_z"][r])
+        assert np.array_equal(got["q_value"].view(np.uint32), g[name + "_q"][r].view(np.uint32))
+        st = np.stack([got["max_deepness"].astype(np.int32), got["tree_size"], got["terminal_count"]], axis=1)
+        assert np.array_equal(st, g[name + "_stats"][r])
+        # winner bookkeeping of compute_elo (self_play.py:336-338)
+        n0, n1 = match_winners(got, (7, 9))
+        exp0 = exp1 = 0
+        for gi, gg in enumerate(games):
+            rr = gg["rows"]
+            win = rr[g[name + "_z"][rr] == 1]
+            if len(win):
+                model = int(g[name + "_player"][win[0]]) ^ (gi & 1)
+                exp0 += model == 0
+                exp1 += model == 1
+        assert (n0, n1) == (exp0, exp1)
+        e.close()
+
+
+def test_compute_elo_two_networks():
+    """compute_elo mirror with two different ResNetZero nets on the MFMA path."""
+    import torch
+    from dotsboxesaz_amd import nn as dnn
+    from dotsboxesaz_amd.self_play import compute_elo
+    torch.manual_seed(0)
+    pa = dnn.resnet_params(3, 3, 32, 2)
+    pb = dnn.resnet_params(3, 3, 16, 1)
+    for p in (pa, pb):
+        p["self_play"] = {"reuse_mcts_tree": True, "noise": [0.8, 0.25],
+                          "mcts": {"mcts_num_read": 100, "mcts_cpuct": [1.25, 19652], "temperature": {0: 1.0, 12: 0.02}}}
+    elo_params = {"n_games": 24, "self_play_override": {"reuse_mcts_tree": False, "noise": [0.0, 0.0],
+                                                       "mcts": {"mcts_num_read": 30}}}
+    e0, e1, wins1 = compute_elo(elo_params, [pa, pb], [0, 0], (1000.0, 1000.0), nn_classes=[dnn.ResNetZero, dnn.ResNetZero],
+                                rows=3, cols=3, n_slots=8)
+    assert abs((e0 - 1000.0) + (e1 - 1000.0)) < 1e-9  # zero-sum update
+    assert np.isnan(wins1) or 0.0 <= wins1 <= 1.0
