@@ -7,9 +7,12 @@
 The tree lives on the GPU (one engine slot, external-evaluator mode): select / expand /
 backup / re-root are the HIP kernels; `async_nn(game_state) -> (p[A], v[1])` is any python
 coroutine, as in the reference.  Semantics are the reference's sequential ones
-(max_pending_evals = 1); `max_pending_evals` and `time_limit` are accepted and ignored.
+(max_pending_evals = 1; the argument is accepted and ignored).  `time_limit` works as in the
+reference (mcts.py:201-203,232-233): the wall clock is checked before every read, default
+120 s; players.AZPlayer's `UCT_search(root, int(1e12), ..., time_limit=t)` pattern is supported.
 Dirichlet noise is drawn from numpy's global RNG exactly where the reference draws it.
 """
+import time
 from collections import namedtuple
 
 import numpy as np
@@ -114,7 +117,9 @@ async def UCT_search(root_node, num_reads, async_nn, cpuct=(1.25, 19652), max_pe
     # drive select / evaluate / expand+backup by hand so that async_nn can be awaited
     import ctypes as C
     from . import _lib
-    nr = np.full(1, int(num_reads), np.int32)
+    end_time = time.time() + (time_limit if time_limit else 120)  # mcts.py:201-203
+    nr = np.full(1, int(min(int(num_reads), 2 ** 31 - 1)), np.int32)
+    first = not root_node.is_expanded  # the root expansion is not subject to the clock (mcts.py:207-208)
     e._ck(e._L.dbaz_search_begin(e.h, nr.ctypes.data, noise.ctypes.data if noise is not None else None))
     x = np.zeros((1, 3, e.H, e.W), np.int16)
     need = np.zeros(1, np.uint8)
@@ -122,6 +127,9 @@ async def UCT_search(root_node, num_reads, async_nn, cpuct=(1.25, 19652), max_pe
     P = np.zeros((1, e.A), np.float32)
     V = np.zeros(1, np.float32)
     while True:
+        if not first and time.time() > end_time:  # mcts.py:232-233: silent early exit
+            break
+        first = False
         e._ck(e._L.dbaz_select(e.h, C.byref(na), x.ctypes.data, need.ctypes.data))
         if na.value == 0:
             break

@@ -125,3 +125,26 @@ def test_generate_games_driver_contract():
     assert set(np.unique(df["z"])) <= {-1, 0, 1}
     first = df.xs(0, level="move_idx")
     assert (first["move"] == -1).all() and (first["player"] == 0).all()
+
+
+def test_uct_search_time_limit_like_az_player():
+    """players.AZPlayer: UCT_search(root, int(1e12), nn, time_limit=t) -- stops on the clock,
+    returns the visits so far, and the tree stays usable (init_mcts_tree + another search)."""
+    import time
+    from dotsboxesaz_amd.game import BoxesState
+    from dotsboxesaz_amd import mcts
+    BoxesState.init_static_fields(((3, 3),))
+
+    async def nn(state):
+        return np.ones(32, np.float32), np.zeros(1, np.float32)
+
+    root = mcts.create_root_uct_node(BoxesState())
+    t0 = time.time()
+    vis = run(mcts.UCT_search(root, int(1e12), nn, (1.25, 19652), 64, (0.0, 0.0), time_limit=0.3))
+    dt = time.time() - t0
+    assert 0.25 < dt < 3.0 and vis.sum() > 10
+    mv = int(np.argmax(vis))
+    root = mcts.init_mcts_tree(root, mv, reuse_tree=True)
+    vis2 = run(mcts.UCT_search(root, 20, nn, (1.25, 19652), 1, (0.0, 0.0)))
+    assert vis2.sum() >= 20 and vis2[mv] == 0
+    root._e.close()
