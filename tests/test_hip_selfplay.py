@@ -254,3 +254,53 @@ def test_compute_elo_two_networks():
                                 rows=3, cols=3, n_slots=8)
     assert abs((e0 - 1000.0) + (e1 - 1000.0)) < 1e-9  # zero-sum update
     assert np.isnan(wins1) or 0.0 <= wins1 <= 1.0
+
+
+def test_baseline_config0_reference_game_with_recorded_network_outputs():
+    """BASELINE configs[0]: the reference's CPU self-play game (3x3, 25 sims/move, ResNetZero,
+    noise (0.8, 0.25), tree reuse, np.random.seed(0)).  The device tree kernels replay it through the
+    external-evaluator path, fed the (p, v) the reference's network returned for every leaf (recorded
+    by position hash) plus its sampled moves and Dirichlet vectors: visit counts, pi, q and TreeStats
+    of every move must equal the reference's get_datasets() rows bit for bit."""
+    from dotsboxesaz_amd.engine import Engine
+    g = _G
+    name = "sp33_resnet"
+    table = {}
+    for k, p, v in zip(g[name + "_evalkeys"], g[name + "_evalp"], g[name + "_evalv"]):
+        table[tuple(int(x) for x in k)] = (p, v)
+
+    def evaluate(x):
+        P, V = [], []
+        for f in x:
+            bits = 0
+            for i in np.nonzero(f[:2].ravel())[0]:
+                bits |= 1 << int(i)
+            key = tuple((bits >> (64 * w)) & (2 ** 64 - 1) for w in range(4)) + ((int(f[2, 0, 0]) + 512) & (2 ** 64 - 1),)
+            p, v = table[key]
+            P.append(p)
+            V.append(v)
+        return np.stack(P), np.array(V).reshape(-1)
+
+    e = Engine(3, 3, 1, mcts_num_read=25, noise=(0.8, 0.25), reuse_tree=True, evaluator="external")
+    e.set_positions(None)
+    moves, noise = g[name + "_drawn_moves"], g[name + "_drawn_noise"]
+    assert len(moves) == len(g[name + "_z"])
+    for ply in range(len(moves)):
+        e.set_search_params((1.25, 19652), (0.8, 0.25))
+        e.search_external(evaluate, num_reads=None, noise=noise[ply][None])
+        r = e.roots()
+        vis = r["visits"][0]
+        pi = vis / (vis.sum() or 1.0)
+        assert np.array_equal(pi.view(np.uint64), g[name + "_pi"][ply].view(np.uint64)), ply
+        assert list(r["stats"][0]) == list(g[name + "_stats"][ply]), ply
+        assert r["q"][0].view(np.uint32) == g[name + "_q"][ply].view(np.uint32), ply
+        st = e.root_states()
+        assert st["to_play"][0] == g[name + "_player"][ply]
+        assert np.array_equal(e.rules_features(st)[0].ravel(), g[name + "_x"][ply])
+        e.advance([int(moves[ply])], True)
+    st = e.root_states()
+    assert st["result"][0] in (0, 1)
+    winner = st["just_played"][0]
+    z = np.where(g[name + "_player"] == winner, st["result"][0], -st["result"][0])
+    assert np.array_equal(z, g[name + "_z"])
+    e.close()
