@@ -201,7 +201,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # launched by torch.distributed.run
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -252,21 +252,33 @@ def main():
         if exp_per_game:
             out["games_per_sec_est"] = out["value"] / exp_per_game
             out["expansions_per_game_assumed"] = exp_per_game
+        # tree kernels: HBM roofline with SURVEY 8d's algorithmic bytes per simulation at the measured path length
+        A = 2 * HW
+        L = spath / max(1, exp)
+        bps = (L - 1) * (12 * A + A / 4 + 12) + L * 16 + (12 * A + (A + 7) // 8 + 8) + 2 * (3 * HW * 4) + 4 * A + 4
         if args.evaluator == "resnet" and m["ms_nn_tower"] > 0:
             out["roofline"] = tower_roofline(args, m, args.steps, args.precision)
+            t_tree = (m["ms_total"] - m["ms_nn_tower"]) * 1e-3  # tree kernels + head FC
+            out["roofline_tree"] = {"bound": "hbm", "kernel": "k_select+k_expand_backup (+k_head_fc in the time)",
+                                    "achieved": exp * bps / t_tree / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                    "frac": exp * bps / t_tree / 1e9 / 8000.0, "bytes_per_sim": bps,
+                                    "note": "latency-bound pointer chase (one wave per game, ~L dependent node "
+                                            "visits per sim); a low HBM fraction is expected (SURVEY 8d)"}
             pmc = os.path.join(REPO, "profiles", "r01_pmc_tower.json")
             if os.path.exists(pmc) and args.precision == 1 and (args.board, args.slots) == (6, 8192):
                 t = json.load(open(pmc))
                 out["roofline"]["traffic"] = t.get("traffic_bytes_per_launch")
                 out["roofline"]["traffic_note"] = t.get("note")
                 out["roofline"]["mfma_busy_frac"] = t.get("mfma_busy_frac")
+                ks = t.get("kernels", {})
+                if "k_select" in ks and "k_expand_backup" in ks:  # same PMC passes, tree kernels
+                    out["roofline_tree"]["traffic"] = sum(
+                        (2.0 * ks[k]["FETCH_SIZE"]["mean"] + ks[k]["WRITE_SIZE"]["mean"]) * 1024.0
+                        for k in ("k_select", "k_expand_backup"))
+                    out["roofline_tree"]["algorithmic_bytes_per_step"] = bps * exp / args.steps
             else:
                 out["roofline"]["traffic"] = None
         else:
-            # tree kernels only: HBM roofline with SURVEY 8d's algorithmic bytes per simulation
-            A = 2 * HW
-            L = spath / max(1, exp)
-            bps = (L - 1) * (12 * A + A / 4 + 12) + L * 16 + (12 * A + (A + 7) // 8 + 8) + 2 * (3 * HW * 4) + 4 * A + 4
             ach = exp * bps / (m["ms_total"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_select+k_expand_backup", "achieved": ach, "peak": 8000.0,
                                "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "bytes_per_sim": bps}
