@@ -14,6 +14,8 @@ Outputs are data only (inputs + the reference's outputs):
                    under a formula-defined evaluator                           (M1-M9)
     nn.npz         ResNetZero / SimpleNN outputs on committed / seeded weights  (N1-N3)
     selfplay.npz   SelfPlay.play_game + get_datasets with recorded RNG draws    (D1-D3)
+    match.npz      two-model match play rows (self_play.compute_elo's loop)     (8f-3)
+    train.npz      SymmetriesGenerator, dataset build, DataLoader epoch, train  (8f-1)
 """
 import argparse
 import asyncio
@@ -526,9 +528,179 @@ def gen_match():
     print("match.npz", len(cases), "cases")
 
 
+# ---------------------------------------------------------------- training data path
+def gen_train():
+    """SymmetriesGenerator (dots_boxes_nn.py:11-58) for each of its 8 transforms; the array build of
+    HDFStoreDataset (utils/utils.py:66-80: training filter, df.sample, pos_average groupby-mean)
+    applied to rows the reference's SelfPlay produced (the HDF read itself needs pytables, which the
+    image lacks, so those pandas statements are executed here on the in-memory DataFrame); one
+    shuffled DataLoader epoch with symmetries (nn.py:186-216); AlphaZeroLoss and
+    NeuralNetWrapper.train on a small ResNetZero (nn.py:131-138,175-295)."""
+    import random
+    import tempfile
+    import pandas as pd
+    import self_play as ref_sp
+    import nn as ref_nn
+    from dots_boxes.dots_boxes_nn import SymmetriesGenerator
+    from utils import utils as ref_utils
+    from utils.utils import DotDict
+    from torch.utils import data
+    out = {}
+    symm = SymmetriesGenerator()
+    o_randint = random.randint
+    # ---- (a) the 8 transforms
+    for (rows, cols) in ((3, 3), (6, 6)):
+        H, W = rows + 1, cols + 1
+        rs = np.random.RandomState(100 + rows)
+        boards = rs.randint(-3, 9, size=(5, 3, H, W)).astype(np.float32)
+        pol = rs.rand(5, 2 * H * W).astype(np.float32)
+        k = "sym%d%d_" % (rows, cols)
+        out[k + "boards"], out[k + "pol"] = boards, pol
+        for sym in range(8):
+            random.randint = lambda a, b, _s=sym: _s
+            try:
+                b2, p2 = symm(torch.tensor(boards), torch.tensor(pol))
+            finally:
+                random.randint = o_randint
+            out[k + "boards_out%d" % sym] = b2.numpy().copy()
+            out[k + "pol_out%d" % sym] = p2.numpy().copy()
+    # ---- (b) dataset build on reference self-play rows (3x3, 10 games, 25 sims)
+    set_board(3, 3)
+    params = DotDict({"self_play": {"reuse_mcts_tree": True, "noise": [0.8, 0.25],
+                                    "mcts": {"mcts_num_read": 25, "mcts_cpuct": [1.25, 19652],
+                                             "temperature": {0: 1.0, 6: 0.02}, "max_async_searches": 1}}})
+    np.random.seed(21)
+    sp = ref_sp.SelfPlay(make_async_formula(0), params)
+    run(sp.play_games(BoxesState(), list(range(10))))
+    df0 = sp.get_datasets(2, with_features=True)
+    A, F = 32, 48
+    xcols = ["x_%d" % i for i in range(F)]
+    picols = ["pi_%d" % i for i in range(A)]
+    # visit counts are not a column of the reference's table: recover them from the nodes the way
+    # get_datasets does (self_play.py:113-115) so that the packed replay rows can be rebuilt
+    vis = []
+    for idx, nodes, z in sp.played_games:
+        for n in nodes[:-1]:
+            vis.append(np.asarray(n.child_number_visits, dtype=np.int64).copy())
+    vis = np.stack(vis)
+    assert np.array_equal(vis / vis.sum(1, keepdims=True), df0[picols].to_numpy())
+    out["ds_x"] = df0[xcols].to_numpy().astype(np.int16)
+    out["ds_visits"] = vis.astype(np.int32)
+    out["ds_z"] = df0["z"].to_numpy().astype(np.int8)
+    out["ds_game_idx"] = df0.reset_index()["game_idx"].to_numpy().astype(np.int32)
+    out["ds_move_idx"] = df0.reset_index()["move_idx"].to_numpy().astype(np.int16)
+    df0 = df0.assign(rowid=np.arange(len(df0)))
+    # coach.py:59-65 (DataFrame.append of old pandas == concat)
+    np.random.seed(22)
+    train = df0.sample(frac=0.9).assign(training=1)
+    val = df0[~df0.index.isin(train.index)].assign(training=-1)
+    new_samples = pd.concat([train, val]).astype({"training": np.int8})
+    for flag, name in ((1, "train"), (-1, "val")):
+        for avg in (False, True):
+            np.random.seed(23)
+            df = new_samples[new_samples.training == flag]          # utils.py:67
+            df = df.sample(min(int(1e12), df.shape[0]))             # utils.py:68
+            order = df["rowid"].to_numpy().astype(np.int32)
+            cols_ = df.columns
+            features_cols = list(c for c in cols_ if c.startswith("x_"))
+            if avg:
+                df = df.groupby(features_cols).mean().reset_index()  # utils.py:72-73
+            k = "ds_%s_%s_" % (name, "avg" if avg else "raw")
+            out[k + "order"] = order
+            out[k + "features"] = df[features_cols].values.astype(np.float32).reshape(-1, 3, 4, 4)
+            out[k + "policy"] = df[list(c for c in cols_ if c.startswith("pi_"))].values.astype(np.float32)
+            out[k + "value"] = df.z.values.astype(np.float32)
+            print("  ", k, len(order), "->", len(df))
+    # ---- (c) one DataLoader epoch: shuffle, drop_last, symmetries (nn.py:186-216)
+    ds = ref_utils.HDFStoreDataset.__new__(ref_utils.HDFStoreDataset)
+    data.Dataset.__init__(ds)
+    ds.features = out["ds_train_avg_features"]
+    ds.policy = out["ds_train_avg_policy"]
+    ds.value = out["ds_train_avg_value"]
+    torch.manual_seed(31)
+    random.seed(32)
+    drawn = []
+
+    def rec_randint(a, b):
+        r = o_randint(a, b)
+        drawn.append(r)
+        return r
+
+    random.randint = rec_randint
+    try:
+        bs = 16
+        loader = data.DataLoader(ds, bs, shuffle=True, drop_last=True)
+        ep_b, ep_p, ep_z = [], [], []
+        for epoch in range(2):
+            for boards, pi, z in loader:
+                boards, pi = symm(boards, pi)
+                ep_b.append(boards.numpy().copy()); ep_p.append(pi.numpy().copy()); ep_z.append(z.numpy().copy())
+    finally:
+        random.randint = o_randint
+    out["ld_boards"], out["ld_pi"], out["ld_z"] = np.stack(ep_b), np.stack(ep_p), np.stack(ep_z)
+    out["ld_syms"] = np.array(drawn, dtype=np.int32)
+    out["ld_cfg"] = np.array([31, 32, bs, 2], dtype=np.int64)
+    # ---- (d) AlphaZeroLoss + NeuralNetWrapper.train (generation 1: min(2*1, nb_epochs) epochs)
+    torch.set_num_threads(1)
+    tmp = tempfile.mkdtemp(prefix="dbaz_golden_")
+    p = ref_resnet_params(3, 3, 16, 2, 4, 8)
+    p.nn.chkpts_filename = os.path.join(tmp, "model_gen{}.pt")
+    p.nn.train_params = DotDict({"nb_epochs": 2, "train_batch_size": 16, "val_batch_size": 16, "lr": 1e-2,
+                                 "optimizer_params": {"momentum": 0.9, "weight_decay": 1e-4},
+                                 "symmetries": symm})
+    torch.manual_seed(41)
+    model = ref_nn.ResNetZero(p)
+    nn_ref.randomize_bn(model, 42)
+    opt0 = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    ref_nn.save_checkpoint(p.nn.chkpts_filename.format(0), model, opt0, 7)
+    sd0 = {k_: v.detach().clone() for k_, v in model.state_dict().items()}
+    for k_, v in sd0.items():
+        out["tr_sd0/" + k_] = v.numpy()
+    crit = ref_nn.AlphaZeroLoss()
+    model.train(False)
+    xb = torch.tensor(out["ld_boards"][0]); pib = torch.tensor(out["ld_pi"][0]); zb = torch.tensor(out["ld_z"][0])
+    pp, vv = model(xb)
+    loss, (lpi, lv) = crit(pp, vv, pib, zb)
+    out["tr_loss_eval"] = np.array([loss.item(), lpi, lv], dtype=np.float64)
+
+    class W:
+        def __init__(self):
+            self.scalars = []
+
+        def add_scalar(self, tag, v, i):
+            self.scalars.append((tag, float(v), int(i)))
+
+        def add_scalars(self, tag, d, i):
+            for k_, v in sorted(d.items()):
+                self.scalars.append((tag + "/" + k_, float(v), int(i)))
+
+    val_ds = ref_utils.HDFStoreDataset.__new__(ref_utils.HDFStoreDataset)
+    data.Dataset.__init__(val_ds)
+    # validation uses batches of 16 with drop_last: give it >= 16 rows (train rows reused)
+    val_ds.features, val_ds.policy, val_ds.value = ds.features[:40], ds.policy[:40], ds.value[:40]
+    wr = W()
+    wrapper = ref_nn.NeuralNetWrapper(ref_nn.ResNetZero(p), p)
+    torch.manual_seed(51)
+    random.seed(52)
+    last = wrapper.train(ds, val_ds, wr, 1)
+    out["tr_last_batch_idx"] = np.array([last], dtype=np.int64)
+    out["tr_scalar_tags"] = np.array([t for t, _, _ in wr.scalars])
+    out["tr_scalar_vals"] = np.array([v for _, v, _ in wr.scalars], dtype=np.float64)
+    out["tr_scalar_steps"] = np.array([i for _, _, i in wr.scalars], dtype=np.int64)
+    ck = torch.load(p.nn.chkpts_filename.format(1), map_location="cpu", weights_only=True)
+    for k_, v in ck["model_dict"].items():
+        out["tr_sd1/" + k_] = v.numpy()
+    out["tr_ck_keys"] = np.array(sorted(ck.keys()))
+    out["tr_cfg"] = np.array([51, 52, 16, 2], dtype=np.int64)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(HERE, "train.npz"), **out)
+    print("train.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="rules,boards,mcts,nn,selfplay,match")
+    ap.add_argument("--only", default="rules,boards,mcts,nn,selfplay,match,train")
     args = ap.parse_args()
     todo = args.only.split(",")
     if "rules" in todo:
@@ -543,3 +715,5 @@ if __name__ == "__main__":
         gen_selfplay()
     if "match" in todo:
         gen_match()
+    if "train" in todo:
+        gen_train()
