@@ -20,6 +20,7 @@ UNITS = [
     ("tree.hip", ["-ffp-contract=off"]),
     ("engine.hip", []),
     ("nn.hip", []),
+    ("replay.hip", ["-ffp-contract=off"]),  # Kahan-compensated float64 means (pandas group_mean)
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -50,7 +51,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
         return r.stdout
 
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         outs = list(ex.map(run, jobs))
     if verbose:
         for o in outs:

@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "nn.h"
+#include "replay.h"
 #include "tree.h"
 
 static std::string g_create_error;
@@ -56,6 +57,7 @@ struct dbaz_engine {
     // packed replay rows
     void *replay_dev = nullptr;
     size_t replay_bytes = 0;
+    ReplayDS *rds = nullptr;    // training data path (replay.hip), created on first use
 };
 
 static int set_error(dbaz_engine *e, int code, const char *fmt, ...)
@@ -274,6 +276,7 @@ extern "C" void dbaz_destroy(dbaz_engine *e)
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stage) (void)hipFree(e->stage);
     if (e->replay_dev) (void)hipFree(e->replay_dev);
+    if (e->rds) rds_destroy(e->rds);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ev_t0) (void)hipEventDestroy(e->ev_t0);
     if (e->ev_t1) (void)hipEventDestroy(e->ev_t1);
@@ -1028,5 +1031,71 @@ extern "C" int dbaz_replay_rows_dev(dbaz_engine *e, void **rows_dev, int32_t *n_
     *rows_dev = e->replay_dev;
     *n_rows = n;
     *row_bytes = rb;
+    return DBAZ_OK;
+}
+
+// ---- training data path (replay.hip) ---------------------------------------------------------
+static Geo make_geo(int rows, int cols)
+{
+    Geo g;
+    memset(&g, 0, sizeof(g));
+    g.rows = rows; g.cols = cols; g.H = rows + 1; g.W = cols + 1; g.HW = g.H * g.W; g.A = 2 * g.HW;
+    return g;
+}
+
+#define RDS(e)                                                                          \
+    do {                                                                                \
+        if (!(e)) return DBAZ_EINVAL;                                                   \
+        USE_DEVICE(e);                                                                  \
+        if (!(e)->rds) (e)->rds = rds_create((e)->g);                                   \
+    } while (0)
+#define RDS_RET(e, call)                                                                \
+    do {                                                                                \
+        std::string _err;                                                               \
+        int _rc = (call);                                                               \
+        if (_rc) return set_error(e, _rc, "%s", _err.c_str());                          \
+        return DBAZ_OK;                                                                 \
+    } while (0)
+
+extern "C" int dbaz_dataset_begin(dbaz_engine *e)
+{
+    RDS(e);
+    RDS_RET(e, rds_begin(e->rds, _err));
+}
+extern "C" int dbaz_dataset_add_rows(dbaz_engine *e, const void *rows_dev, int64_t n_rows, int32_t row_bytes, const int32_t *sel,
+                                     int64_t n_sel)
+{
+    RDS(e);
+    HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
+    RDS_RET(e, rds_add_rows(e->rds, e->stream, rows_dev, n_rows, row_bytes, sel, n_sel, _err));
+}
+extern "C" int dbaz_dataset_finish(dbaz_engine *e, int32_t pos_average, const int32_t *order, int64_t *n_out)
+{
+    RDS(e);
+    RDS_RET(e, rds_finish(e->rds, e->stream, pos_average, order, n_out, _err));
+}
+extern "C" int dbaz_dataset_fetch(dbaz_engine *e, int16_t *x, float *pi, float *z)
+{
+    RDS(e);
+    RDS_RET(e, rds_fetch(e->rds, e->stream, x, pi, z, _err));
+}
+extern "C" int dbaz_dataset_batch(dbaz_engine *e, const int32_t *idx, int32_t n, int32_t sym, float *boards_dev, float *pi_dev,
+                                  float *z_dev)
+{
+    RDS(e);
+    RDS_RET(e, rds_batch(e->rds, e->stream, idx, n, sym, boards_dev, pi_dev, z_dev, _err));
+}
+extern "C" int dbaz_symmetry_apply(dbaz_engine *e, int32_t sym, const float *boards_in_dev, const float *pol_in_dev, int64_t n,
+                                   float *boards_out_dev, float *pol_out_dev)
+{
+    RDS(e);
+    RDS_RET(e, rds_symmetry_apply(e->rds, e->stream, sym, boards_in_dev, pol_in_dev, n, boards_out_dev, pol_out_dev, _err));
+}
+extern "C" int dbaz_symmetry_table(int32_t rows, int32_t cols, int32_t sym, int32_t *lut_out)
+{
+    if (rows < 1 || cols < 1 || !lut_out) return set_error(nullptr, DBAZ_EINVAL, "bad arguments");
+    std::string err;
+    int rc = rds_symmetry_lut(make_geo(rows, cols), sym, lut_out, err);
+    if (rc) return set_error(nullptr, rc, "%s", err.c_str());
     return DBAZ_OK;
 }

@@ -300,3 +300,81 @@ class Engine:
         ptr, n, rb = C.c_void_p(), C.c_int32(), C.c_int32()
         self._ck(self._L.dbaz_replay_rows_dev(self.h, C.byref(ptr), C.byref(n), C.byref(rb)))
         return ptr.value, n.value, rb.value
+
+    # ---- training data path: replay rows in HBM -> dataset -> batches in HBM
+    @property
+    def row_bytes(self):
+        return (28 + self.F * 2 + self.A * 4 + 7) // 8 * 8
+
+    def dataset_begin(self):
+        self._ck(self._L.dbaz_dataset_begin(self.h))
+
+    def dataset_add_rows(self, rows, sel=None):
+        """rows: (device pointer, n_rows, row_bytes) as returned by replay_rows_dev(), or any object
+        with data_ptr()/shape (a torch uint8 CUDA tensor [n, row_bytes], e.g. the all-gathered
+        replay).  sel: host int32 row indices in dataset order (None = all rows)."""
+        if isinstance(rows, tuple):
+            ptr, n, rb = rows
+        else:
+            if not rows.is_cuda or not rows.is_contiguous():
+                raise ValueError("replay rows must be a contiguous CUDA tensor")
+            ptr, n, rb = rows.data_ptr(), int(rows.shape[0]), int(rows.shape[1])
+        s, ns = None, 0
+        if sel is not None:
+            s = np.ascontiguousarray(sel, dtype=np.int32)
+            ns = len(s)
+        self._ck(self._L.dbaz_dataset_add_rows(self.h, C.c_void_p(ptr), C.c_int64(n), C.c_int32(rb), C.c_void_p(_p(s)),
+                                               C.c_int64(ns)))
+
+    def dataset_finish(self, pos_average=False, order=None):
+        """order: dataset order as a permutation of the staged rows (None = staging order)."""
+        n = C.c_int64()
+        o = np.ascontiguousarray(order, dtype=np.int32) if order is not None else None
+        self._ck(self._L.dbaz_dataset_finish(self.h, C.c_int32(1 if pos_average else 0), C.c_void_p(_p(o)), C.byref(n)))
+        self._ds_n = n.value
+        return n.value
+
+    def dataset_fetch(self):
+        """Host copies (features int16 [n,3HW], policy float32 [n,A], value float32 [n])."""
+        n = getattr(self, "_ds_n", 0)
+        x = np.empty((n, self.F), dtype=np.int16)
+        pi = np.empty((n, self.A), dtype=np.float32)
+        z = np.empty(n, dtype=np.float32)
+        self._ck(self._L.dbaz_dataset_fetch(self.h, C.c_void_p(_p(x)), C.c_void_p(_p(pi)), C.c_void_p(_p(z))))
+        return x, pi, z
+
+    def dataset_batch(self, idx, sym=0):
+        """Rows idx of the dataset under symmetry sym as torch CUDA tensors
+        (boards float32 [n,3,H,W], pi [n,A], z [n,1]) -- written by the HIP kernel, no host copy."""
+        import torch
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        n = len(idx)
+        dev = torch.device("cuda", self.cfg.device)
+        boards = torch.empty((n, 3, self.H, self.W), dtype=torch.float32, device=dev)
+        pi = torch.empty((n, self.A), dtype=torch.float32, device=dev)
+        z = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        self._ck(self._L.dbaz_dataset_batch(self.h, C.c_void_p(_p(idx)), C.c_int32(n), C.c_int32(sym),
+                                            C.c_void_p(boards.data_ptr()), C.c_void_p(pi.data_ptr()), C.c_void_p(z.data_ptr())))
+        return boards, pi, z
+
+    def symmetry_apply(self, sym, boards=None, policies=None):
+        """SymmetriesGenerator transform `sym` of torch CUDA float32 tensors (out of place)."""
+        import torch
+        n = int((boards if boards is not None else policies).shape[0])
+        for t in (boards, policies):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+                raise ValueError("symmetry_apply needs contiguous float32 CUDA tensors")
+        torch.cuda.current_stream(boards.device if boards is not None else policies.device).synchronize()
+        bo = torch.empty_like(boards) if boards is not None else None
+        po = torch.empty_like(policies) if policies is not None else None
+        dp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        self._ck(self._L.dbaz_symmetry_apply(self.h, C.c_int32(sym), dp(boards), dp(policies), C.c_int64(n), dp(bo), dp(po)))
+        return bo, po
+
+
+def symmetry_table(rows, cols, sym):
+    """src[a'] with out[a'] = in[src[a']] over the two edge planes (host only, no GPU needed)."""
+    L = _lib.load()
+    lut = np.empty(2 * (rows + 1) * (cols + 1), dtype=np.int32)
+    _lib.check(None, L.dbaz_symmetry_table(C.c_int32(rows), C.c_int32(cols), C.c_int32(sym), C.c_void_p(lut.ctypes.data)))
+    return lut

@@ -190,6 +190,34 @@ int dbaz_fetch_samples(dbaz_engine *e, int32_t max_rows, int32_t *n_rows,
  * fixed-stride packed rows, see DESIGN.md "replay row".  Returns a DEVICE pointer. */
 int dbaz_replay_rows_dev(dbaz_engine *e, void **rows_dev, int32_t *n_rows, int32_t *row_bytes);
 
+/* ---- training data path: replay rows in HBM -> dataset -> batches in HBM --------
+ * Replaces utils.HDFStoreDataset's array build (utils/utils.py:61-80), torch's DataLoader gather
+ * and SymmetriesGenerator (dots_boxes/dots_boxes_nn.py:11-58) of the reference's train loop
+ * (nn.py:186-216).  Rows are the packed replay rows of dbaz_replay_rows_dev (this engine's, or
+ * the RCCL all-gathered ones of all ranks); they never leave HBM. */
+int dbaz_dataset_begin(dbaz_engine *e);
+/* append rows sel[0..n_sel) of the packed device rows (sel = HOST int32 indices in the order
+ * the reference's DataFrame would have: where-clause, training flag, df.sample; NULL = all) */
+int dbaz_dataset_add_rows(dbaz_engine *e, const void *rows_dev, int64_t n_rows, int32_t row_bytes,
+                          const int32_t *sel, int64_t n_sel);
+/* order: dataset order as a HOST permutation of the staged rows (NULL = staging order), for
+ * selections that interleave several row buffers.  pos_average != 0: merge rows with identical
+ * features (groupby(x).mean(): Kahan float64 means of pi and z in dataset order; groups in
+ * ascending lexicographic order of the feature columns) */
+int dbaz_dataset_finish(dbaz_engine *e, int32_t pos_average, const int32_t *order, int64_t *n_out);
+/* host copies of the dataset arrays (features int16 [n,3HW], policy float32 [n,A], value [n]) */
+int dbaz_dataset_fetch(dbaz_engine *e, int16_t *x, float *pi, float *z);
+/* one batch: rows idx[0..n) (HOST indices) under symmetry sym (0..7 = SymmetriesGenerator.IDXS)
+ * into caller-owned DEVICE buffers boards float32 [n,3,H,W], pi [n,A], z [n,1]; complete on return */
+int dbaz_dataset_batch(dbaz_engine *e, const int32_t *idx, int32_t n, int32_t sym, float *boards_dev,
+                       float *pi_dev, float *z_dev);
+/* SymmetriesGenerator.forward on DEVICE tensors boards [n,3,H,W] / policies [n,A] (either may be
+ * NULL); out-of-place */
+int dbaz_symmetry_apply(dbaz_engine *e, int32_t sym, const float *boards_in_dev, const float *pol_in_dev,
+                        int64_t n, float *boards_out_dev, float *pol_out_dev);
+/* host only (no handle, no GPU): src[a'] with out[a'] = in[src[a']] over the two edge planes */
+int dbaz_symmetry_table(int32_t rows, int32_t cols, int32_t sym, int32_t *lut_out);
+
 #ifdef __cplusplus
 }
 #endif
