@@ -23,7 +23,7 @@ SYMBOLS = [
     "dbaz_get_roots", "dbaz_get_root_states", "dbaz_advance",
     "dbaz_selfplay_start", "dbaz_selfplay_script", "dbaz_selfplay_fastforward", "dbaz_step", "dbaz_run",
     "dbaz_get_counters", "dbaz_timing_begin", "dbaz_timing_end", "dbaz_fetch_samples", "dbaz_replay_rows_dev",
-    "dbaz_dataset_begin", "dbaz_dataset_add_rows", "dbaz_dataset_finish", "dbaz_dataset_fetch", "dbaz_dataset_batch",
+    "dbaz_replay_rows_clear", "dbaz_dataset_select", "dbaz_dataset_begin", "dbaz_dataset_add_rows", "dbaz_dataset_finish", "dbaz_dataset_fetch", "dbaz_dataset_batch",
     "dbaz_symmetry_apply", "dbaz_symmetry_table",
 ]
 

@@ -57,7 +57,9 @@ struct dbaz_engine {
     // packed replay rows
     void *replay_dev = nullptr;
     size_t replay_bytes = 0;
-    ReplayDS *rds = nullptr;    // training data path (replay.hip), created on first use
+    ReplayDS *rds = nullptr;    // training data path (replay.hip): the selected dataset, created on first use
+    ReplayDS *rds_all[DBAZ_MAX_DATASETS] = {nullptr, nullptr, nullptr, nullptr};
+    int cur_ds = 0;
 };
 
 static int set_error(dbaz_engine *e, int code, const char *fmt, ...)
@@ -276,7 +278,7 @@ extern "C" void dbaz_destroy(dbaz_engine *e)
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stage) (void)hipFree(e->stage);
     if (e->replay_dev) (void)hipFree(e->replay_dev);
-    if (e->rds) rds_destroy(e->rds);
+    for (int i = 0; i < DBAZ_MAX_DATASETS; i++) if (e->rds_all[i]) rds_destroy(e->rds_all[i]);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ev_t0) (void)hipEventDestroy(e->ev_t0);
     if (e->ev_t1) (void)hipEventDestroy(e->ev_t1);
@@ -1047,7 +1049,8 @@ static Geo make_geo(int rows, int cols)
     do {                                                                                \
         if (!(e)) return DBAZ_EINVAL;                                                   \
         USE_DEVICE(e);                                                                  \
-        if (!(e)->rds) (e)->rds = rds_create((e)->g);                                   \
+        if (!(e)->rds_all[(e)->cur_ds]) (e)->rds_all[(e)->cur_ds] = rds_create((e)->g); \
+        (e)->rds = (e)->rds_all[(e)->cur_ds];                                           \
     } while (0)
 #define RDS_RET(e, call)                                                                \
     do {                                                                                \
@@ -1057,6 +1060,21 @@ static Geo make_geo(int rows, int cols)
         return DBAZ_OK;                                                                 \
     } while (0)
 
+extern "C" int dbaz_dataset_select(dbaz_engine *e, int32_t which)
+{
+    if (!e) return DBAZ_EINVAL;
+    if (which < 0 || which >= DBAZ_MAX_DATASETS) return set_error(e, DBAZ_EINVAL, "dataset index must be 0..%d", DBAZ_MAX_DATASETS - 1);
+    e->cur_ds = which;
+    return DBAZ_OK;
+}
+extern "C" int dbaz_replay_rows_clear(dbaz_engine *e)
+{
+    if (!e) return DBAZ_EINVAL;
+    USE_DEVICE(e);
+    HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
+    HIP_CHECK_RET(e, hipMemset(e->B.out_count, 0, 4));
+    return DBAZ_OK;
+}
 extern "C" int dbaz_dataset_begin(dbaz_engine *e)
 {
     RDS(e);

@@ -306,6 +306,15 @@ class Engine:
     def row_bytes(self):
         return (28 + self.F * 2 + self.A * 4 + 7) // 8 * 8
 
+    def replay_rows_clear(self):
+        """Empty the finished-row buffer (the caller keeps the rows it took with replay_rows_dev on the device)."""
+        self._ck(self._L.dbaz_replay_rows_clear(self.h))
+
+    def dataset_select(self, which):
+        """Address dataset `which` (0..3) with the following dataset_* calls."""
+        self._ck(self._L.dbaz_dataset_select(self.h, C.c_int32(which)))
+        self._ds_cur = int(which)
+
     def dataset_begin(self):
         self._ck(self._L.dbaz_dataset_begin(self.h))
 
@@ -331,12 +340,13 @@ class Engine:
         n = C.c_int64()
         o = np.ascontiguousarray(order, dtype=np.int32) if order is not None else None
         self._ck(self._L.dbaz_dataset_finish(self.h, C.c_int32(1 if pos_average else 0), C.c_void_p(_p(o)), C.byref(n)))
-        self._ds_n = n.value
+        self._ds_sizes = getattr(self, "_ds_sizes", {})
+        self._ds_sizes[getattr(self, "_ds_cur", 0)] = n.value
         return n.value
 
     def dataset_fetch(self):
         """Host copies (features int16 [n,3HW], policy float32 [n,A], value float32 [n])."""
-        n = getattr(self, "_ds_n", 0)
+        n = getattr(self, "_ds_sizes", {}).get(getattr(self, "_ds_cur", 0), 0)
         x = np.empty((n, self.F), dtype=np.int16)
         pi = np.empty((n, self.A), dtype=np.float32)
         z = np.empty(n, dtype=np.float32)

@@ -157,3 +157,14 @@ class NeuralNetWrapper:
 
     async def __call__(self, X):
         return await self.predict(X)
+
+    def train(self, train_dataset, val_dataset, writer, generation):
+        """nn.py:175-274.  The optimizer step runs in torch on ROCm (see train.py); batches come from
+        HBM when the datasets are train_data.ReplayDataset objects.  The trained weights are pushed
+        back into the HIP engine so that the next self-play generation uses them."""
+        from . import train as T
+        last = T.train(self.model, self.params, train_dataset, val_dataset, writer, generation,
+                       device="cuda:%d" % self.engine.cfg.device)
+        self.model.to("cpu")
+        self.set_model(self.model)
+        return last

@@ -1,0 +1,186 @@
+"""Training step of the generation loop -- host-side mirror of the reference's
+`NeuralNetWrapper.train` (nn.py:175-274), `AlphaZeroLoss` (nn.py:131-138), checkpoint format
+(nn.py:292-313) and `GenerationLrScheduler` (nn.py:276-289).
+
+What runs where: the DATA side (dataset build from replay rows in HBM, batch gather, symmetries) is
+hand-written HIP (`train_data.py` -> csrc/replay.hip).  The forward/backward/optimizer arithmetic of
+this file is torch on ROCm (MIOpen/rocBLAS autograd) -- plumbing around the product, not a kernel of
+this repository, and never on the self-play path: the weight containers of `nn.py` still refuse
+`forward()`; `training_forward` composes their sub-modules explicitly for autograd.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+from torch import nn as tnn
+
+
+def _get(d, k, default=None):
+    if isinstance(d, dict):
+        return d.get(k, default)
+    return getattr(d, k, default)
+
+
+def training_forward(model, x):
+    """(log_softmax policy, tanh value) of a `nn.ResNetZero` / `nn.SimpleNN` container, in the
+    reference's operation order (nn.py:23-28,48-57,81-86,98-104,117-122; dots_boxes_nn.py:85-98)."""
+    if getattr(model, "kind", None) == "simplenn":
+        for i in range(5):
+            x = getattr(model, "bn%d" % i)(F.relu(getattr(model, "conv%d" % i)(x)))
+        x = x.view(x.size(0), -1)
+        x = model.bn_fc0(F.relu(model.fc0(x)))
+        x = model.bn_fc1(F.relu(model.fc1(x)))
+        return F.log_softmax(model.policy_fc(x), dim=1), torch.tanh(model.value_fc(x))
+    x = model.bn_input(x)
+    r = model.resnet
+    x = F.relu(r.bn0(r.conv0(x)))
+    for blk in r.resblocks:
+        y = F.relu(blk.bn1(blk.conv1(x)))
+        y = blk.bn2(blk.conv2(y))
+        y += x
+        x = F.relu(y)
+    ph, vh = model.policy_head, model.value_head
+    p = F.relu(ph.bn0(ph.conv0(x)))
+    p = F.log_softmax(ph.fc(p.view(p.size(0), -1)), dim=1)
+    v = F.relu(vh.bn0(vh.conv0(x)))
+    v = F.relu(vh.fc0(v.view(v.size(0), -1)))
+    v = torch.tanh(vh.fc1(v))
+    return p, v
+
+
+class AlphaZeroLoss(tnn.Module):
+    """nn.py:131-138: mean squared value error + mean cross entropy against the MCTS policy;
+    returns (loss, (loss_pi, loss_v) as python floats)."""
+
+    def forward(self, p, v, pi, z):
+        loss_v = (z - v).pow(2).mean()
+        loss_pi = -(pi * p).sum(1).mean()
+        return loss_v + loss_pi, (loss_pi.item(), loss_v.item())
+
+
+class GenerationLrScheduler:
+    """nn.py:276-289: the learning rate of the last schedule key <= generation."""
+
+    def __init__(self, schedule):
+        assert schedule is not None
+        self.schedule = schedule
+
+    def __call__(self, generation):
+        lr = None
+        for g in range(generation + 1):
+            if g in self.schedule:
+                lr = self.schedule[g]
+        assert lr is not None
+        return lr
+
+    def __repr__(self):
+        return "GenerationLrScheduler(%s)" % (self.schedule,)
+
+
+def save_checkpoint(filename, model, optimizer, last_batch_idx):
+    """nn.py:292-295: {'last_batch_idx', 'model_dict', 'optimizer_dict'}."""
+    torch.save({"last_batch_idx": last_batch_idx, "model_dict": model.state_dict(),
+                "optimizer_dict": optimizer.state_dict()}, filename)
+
+
+def load_checkpoint(filename, model, optimizer, to_device):
+    """nn.py:296-313 (missing file -> ValueError).  Checkpoints are tensors and plain containers:
+    loaded with weights_only=True."""
+    if not os.path.isfile(filename):
+        raise ValueError("=> no checkpoint found at '%s'" % filename)
+    ck = torch.load(filename, map_location="cpu", weights_only=True)
+    model.load_state_dict(ck["model_dict"])
+    optimizer.load_state_dict(ck["optimizer_dict"])
+    model.to(to_device)
+    for state in optimizer.state.values():
+        for k, v in state.items():
+            if isinstance(v, torch.Tensor):
+                state[k] = v.to(to_device)
+    return ck["last_batch_idx"]
+
+
+def _accuracy(v, z, threshold=0.5):
+    with torch.no_grad():
+        correct = z.sign().eq(v.sign())
+        correct = correct * (v - z).abs().lt(threshold)
+        return correct.sum().item(), z.size()[0]
+
+
+def _batches(dataset, batch_size, shuffle, symmetries, device):
+    """Device fast path when the dataset offers it (train_data.ReplayDataset.loader: ONE HIP kernel
+    per batch gathers, normalises and transforms in HBM); otherwise the reference's own flow: a torch
+    DataLoader over a host dataset, transfer, then `symmetries(boards, pi)` (nn.py:186-216)."""
+    if hasattr(dataset, "loader"):
+        for b in dataset.loader(batch_size, shuffle=shuffle, drop_last=True, symmetries=symmetries):
+            yield b
+        return
+    from torch.utils import data
+    for boards, pi, z in data.DataLoader(dataset, batch_size, shuffle=shuffle, drop_last=True):
+        boards, pi, z = boards.to(device), pi.to(device), z.to(device)
+        if symmetries is not None:
+            boards, pi = symmetries(boards, pi)
+        yield boards, pi, z
+
+
+def train(model, params, train_dataset, val_dataset, writer, generation, device=None):
+    """NeuralNetWrapper.train (nn.py:175-274): SGD(lr, **optimizer_params), resume from the checkpoint
+    of generation-1 when generation > 0, min(2*generation, nb_epochs) epochs of shuffled drop_last
+    batches with a random symmetry each, validation pass per epoch, tensorboard-style scalars,
+    checkpoint of `generation` written at the end.  Returns the last batch index."""
+    nnp = _get(params, "nn")
+    tp = _get(nnp, "train_params")
+    device = torch.device(device if device is not None else
+                          (_get(nnp, "pytorch_device", "cuda:0") if torch.cuda.is_available() else "cpu"))
+    symmetries = _get(tp, "symmetries")
+    model.to(device)
+    criterion = AlphaZeroLoss()
+    optimizer = torch.optim.SGD(model.parameters(), lr=_get(tp, "lr"), **dict(_get(tp, "optimizer_params") or {}))
+    batch_i = 0
+    if generation > 0:
+        batch_i = load_checkpoint(_get(nnp, "chkpts_filename").format(generation - 1), model, optimizer, device)
+    writer.add_scalar("lr", _get(tp, "lr"), batch_i)
+    for epoch in range(min(2 * generation, _get(tp, "nb_epochs"))):
+        model.train(True)
+        tr_loss, tr_batches, tr_ok, tr_tot = 0, 0, 0, 1
+        for boards, pi, z in _batches(train_dataset, _get(tp, "train_batch_size"), True, symmetries, device):
+            batch_i += 1
+            tr_batches += 1
+            p, v = training_forward(model, boards)
+            loss, (loss_pi, loss_v) = criterion(p, v, pi, z)
+            loss.backward()
+            optimizer.step()
+            optimizer.zero_grad()
+            c, t = _accuracy(v, z)
+            tr_ok += c
+            tr_tot += t
+            tr_loss += loss_pi + loss_v
+            writer.add_scalars("loss", {"pi/train": loss_pi, "v/train": loss_v, "total/train": loss_pi + loss_v}, batch_i)
+        val_loss, loss_v, loss_pi, val_ok, val_tot = 0.0, 0.0, 0.0, 0, 1
+        if val_dataset:
+            model.train(False)
+            val_batches = 0
+            for boards, pi, z in _batches(val_dataset, _get(tp, "val_batch_size"), False, symmetries, device):
+                val_batches += 1
+                p, v = training_forward(model, boards)
+                c, t = _accuracy(v, z)
+                val_ok += c
+                val_tot += t
+                _, (_lpi, _lv) = criterion(p, v, pi, z)
+                loss_v += _lv
+                loss_pi += _lpi
+            if val_batches > 0:
+                loss_v /= val_batches
+                loss_pi /= val_batches
+                val_loss = loss_v + loss_pi
+                writer.add_scalars("loss", {"pi/eval": loss_pi, "v/eval": loss_v, "total/eval": val_loss}, batch_i)
+        writer.add_scalars("accuracy", {"v/train": tr_ok / tr_tot, "v/eval": val_ok / val_tot}, batch_i)
+        writer.add_scalar("generation", generation, batch_i)
+        print("Epoch %d, train loss= %5f, validation loss= %5f" % (epoch, tr_loss / max(1, tr_batches), val_loss), flush=True)
+    save_checkpoint(_get(nnp, "chkpts_filename").format(generation), model, optimizer, batch_i)
+    return batch_i
+
+
+def window_where(generation):
+    """coach.py:148-149: generations kept in the training window (`generation >= max(0, g - ws)`)."""
+    ws = max(4, min(4 + (generation - 4) // 2, 20))
+    return max(0, generation - ws)

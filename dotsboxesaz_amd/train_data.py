@@ -47,16 +47,19 @@ class ReplayStore:
         self.chunks.append(dict(generation=int(generation), rows=rows, n=n, train_locs=train_locs.astype(np.int32),
                                 val_locs=np.nonzero(mask)[0].astype(np.int32)))
 
-    def dataset(self, train=True, min_generation=0, n_samples=int(1e12), pos_average=False):
-        return ReplayDataset(self, train, min_generation, n_samples, pos_average)
+    def dataset(self, train=True, min_generation=0, n_samples=int(1e12), pos_average=False, slot=None):
+        """slot: which of the engine's resident datasets to build into (default: 0 for train, 1 for validation)."""
+        return ReplayDataset(self, train, min_generation, n_samples, pos_average, slot)
 
 
 class ReplayDataset:
-    """utils.HDFStoreDataset over rows in HBM.  Building it runs the HIP dataset kernels; one
-    dataset at a time is resident per engine handle (building another replaces it)."""
+    """utils.HDFStoreDataset over rows in HBM.  Building it runs the HIP dataset kernels; an engine
+    handle keeps up to four datasets resident (`slot`); building into a slot replaces its content."""
 
-    def __init__(self, store, train=True, min_generation=0, n_samples=int(1e12), pos_average=False):
+    def __init__(self, store, train=True, min_generation=0, n_samples=int(1e12), pos_average=False, slot=None):
         e = self.engine = store.engine
+        self.slot = (0 if train else 1) if slot is None else int(slot)
+        e.dataset_select(self.slot)
         chunks = [c for c in store.chunks if c["generation"] >= min_generation]
         cand = [(ci, loc) for ci, c in enumerate(chunks) for loc in (c["train_locs"] if train else c["val_locs"])]
         take = _sample_locs(len(cand), min(int(n_samples), len(cand))) if cand else []
@@ -86,6 +89,7 @@ class ReplayDataset:
     def _arrays(self):
         if self._host is None:
             e = self.engine
+            e.dataset_select(self.slot)
             x, pi, z = e.dataset_fetch()
             self._host = (x.astype(np.float32).reshape(-1, 3, e.H, e.W), pi, z)
         return self._host
@@ -125,6 +129,7 @@ class DeviceLoader:
         e = self.ds.engine
         for idx in self._idx:
             sym = self.symmetries.draw() if self.symmetries is not None else 0
+            e.dataset_select(self.ds.slot)
             yield e.dataset_batch(idx.numpy(), sym)
 
 

@@ -189,12 +189,18 @@ int dbaz_fetch_samples(dbaz_engine *e, int32_t max_rows, int32_t *n_rows,
 /* device-resident replay rows for the RCCL all-gather (multi-GPU iteration end):
  * fixed-stride packed rows, see DESIGN.md "replay row".  Returns a DEVICE pointer. */
 int dbaz_replay_rows_dev(dbaz_engine *e, void **rows_dev, int32_t *n_rows, int32_t *row_bytes);
+/* empties the finished-row buffer without a host copy (the caller took the rows on the device) */
+int dbaz_replay_rows_clear(dbaz_engine *e);
 
 /* ---- training data path: replay rows in HBM -> dataset -> batches in HBM --------
  * Replaces utils.HDFStoreDataset's array build (utils/utils.py:61-80), torch's DataLoader gather
  * and SymmetriesGenerator (dots_boxes/dots_boxes_nn.py:11-58) of the reference's train loop
  * (nn.py:186-216).  Rows are the packed replay rows of dbaz_replay_rows_dev (this engine's, or
  * the RCCL all-gathered ones of all ranks); they never leave HBM. */
+#define DBAZ_MAX_DATASETS 4
+/* a handle keeps up to DBAZ_MAX_DATASETS datasets resident (train + validation of the reference's
+ * loop); the dataset calls below address the selected one (default 0) */
+int dbaz_dataset_select(dbaz_engine *e, int32_t which);
 int dbaz_dataset_begin(dbaz_engine *e);
 /* append rows sel[0..n_sel) of the packed device rows (sel = HOST int32 indices in the order
  * the reference's DataFrame would have: where-clause, training flag, df.sample; NULL = all) */

@@ -1,0 +1,70 @@
+"""Generation loop with the replay resident in HBM (dotsboxesaz_amd/coach.py):
+selfplay (HIP) -> ReplayStore -> device dataset/batches (HIP) -> optimizer step (torch on ROCm) ->
+weights back into the HIP engine -> next generation's selfplay -> Elo match play."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class Writer:
+    def __init__(self):
+        self.s = []
+
+    def add_scalar(self, tag, v, i):
+        self.s.append((tag, float(v), int(i)))
+
+    def add_scalars(self, tag, d, i):
+        for k, v in sorted(d.items()):
+            self.s.append((tag + "/" + k, float(v), int(i)))
+
+
+def test_three_generations_on_3x3(tmp_path):
+    import torch
+    from dotsboxesaz_amd import nn as dnn
+    from dotsboxesaz_amd import train as T
+    from dotsboxesaz_amd.coach import Coach
+    params = dnn.resnet_params(3, 3, 32, 2, 4, 8)
+    params["nn"]["model_class"] = dnn.ResNetZero
+    params["nn"]["chkpts_filename"] = str(tmp_path / "model_gen{}.pt")
+    params["nn"]["train_params"] = {"nb_epochs": 3, "train_batch_size": 128, "val_batch_size": 32, "lr": 1e-2,
+                                    "lr_scheduler": T.GenerationLrScheduler({0: 1e-2, 2: 5e-3}),
+                                    "optimizer_params": {"momentum": 0.9, "weight_decay": 1e-4},
+                                    "pos_average": True, "train_split": 0.9, "max_samples_per_gen": 100000,
+                                    "symmetries": None}
+    params["self_play"] = {"num_games": 96, "reuse_mcts_tree": True, "noise": (0.8, 0.25),
+                           "mcts": {"mcts_num_read": 24, "mcts_cpuct": (1.25, 19652), "temperature": {0: 1.0, 6: 0.02}}}
+    params["elo"] = {"n_games": 16, "self_play_override": {"reuse_mcts_tree": False, "noise": (0.0, 0.0),
+                                                           "mcts": {"mcts_num_read": 16}}}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    coach = Coach(params, 3, 3, n_slots=32)
+    w = Writer()
+    log = coach.learn_to_play(0, 2, writer=w)
+    assert [r["generation"] for r in log] == [0, 1, 2]
+    assert all(r["selfplay"]["rows"] > 96 * 8 for r in log)
+    assert len(coach.store.chunks) == 3
+    # generation 0 trains 0 epochs (min(2*0, nb_epochs)), generation 1 two, generation 2 three
+    n_train = [len(c["train_locs"]) for c in coach.store.chunks]
+    assert log[0]["last_batch_idx"] == 0 and log[1]["last_batch_idx"] > 0 and log[2]["last_batch_idx"] > log[1]["last_batch_idx"]
+    cks = [torch.load(params["nn"]["chkpts_filename"].format(g), map_location="cpu", weights_only=True) for g in range(3)]
+    assert [c["last_batch_idx"] for c in cks] == [r["last_batch_idx"] for r in log]
+    k = "resnet.conv0.weight"
+    assert not torch.equal(cks[0]["model_dict"][k], cks[1]["model_dict"][k])
+    assert not torch.equal(cks[1]["model_dict"][k], cks[2]["model_dict"][k])
+    losses = [v for t, v, _ in w.s if t == "loss/total/train"]
+    assert len(losses) == log[2]["last_batch_idx"] and np.all(np.isfinite(losses))
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])            # it learns something on its own games
+    assert [v for t, v, _ in w.s if t == "lr"] == [1e-2, 1e-2, 5e-3]
+    assert "elo" in log[1] and "wins" in log[2] and sum(n_train) > 0
+    # the engine now holds generation 2's weights: HIP predict == torch eval forward of the checkpoint
+    model = dnn.ResNetZero(params)
+    model.load_state_dict(cks[2]["model_dict"])
+    model.train(False)
+    x = np.random.RandomState(1).randint(0, 2, size=(64, 3, 4, 4)).astype(np.float32)
+    x[:, 2] = 4.0
+    with torch.no_grad():
+        lp, v = T.training_forward(model, torch.tensor(x))
+    p_hip, v_hip = coach.engine.predict(x)
+    assert np.max(np.abs(p_hip - np.exp(lp.numpy()))) < 1e-4 and np.max(np.abs(v_hip - v.numpy())) < 1e-4
+    coach.close()
