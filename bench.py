@@ -159,6 +159,75 @@ def full_games(args, rank, local_rank, world, torch):
     eng.close()
 
 
+def train_data_bench(args, local_rank, torch):
+    """Training DATA path on synthetic replay rows resident in HBM: dataset build
+    (stage + stable radix sort + Kahan group means = HDFStoreDataset with pos_average) and batch
+    assembly (gather + symmetry).  HBM roofline; algorithmic bytes per row stated in DESIGN.md."""
+    from dotsboxesaz_amd.engine import Engine
+    rows = cols = args.board
+    e = Engine(rows, cols, 4, mcts_num_read=8, evaluator="formula", nodes_per_slot=64, device=local_rank)
+    dev = torch.device("cuda", local_rank)
+    n, F, A, HW, rb = args.train_data, e.F, e.A, e.H * e.W, e.row_bytes
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    # positions drawn from a pool a quarter the size of the row count (duplicates as in real replay windows)
+    pool = max(1, n // 4)
+    edges = (torch.rand((pool, A), device=dev, generator=g) < 0.4).to(torch.int16)
+    sent = torch.zeros(A, dtype=torch.bool, device=dev)
+    sent.view(2, e.H, e.W)[1, e.H - 1, :] = True
+    sent.view(2, e.H, e.W)[0, :, e.W - 1] = True
+    edges[:, sent] = 0
+    plane2 = torch.randint(0, 2 * rows * cols, (pool, 1), device=dev, generator=g, dtype=torch.int16).expand(pool, HW)
+    xpool = torch.cat([edges, plane2], dim=1).contiguous()
+    pick = torch.randint(0, pool, (n,), device=dev, generator=g)
+    x = xpool[pick]
+    vis = torch.randint(0, 50, (n, A), device=dev, generator=g, dtype=torch.int32) * (1 - x[:, :A].to(torch.int32))
+    vis[:, 0] += 1
+    buf = torch.zeros((n, rb), dtype=torch.uint8, device=dev)
+    buf[:, 25] = torch.randint(0, 3, (n,), device=dev, generator=g).to(torch.uint8) - 1  # z in {-1,0,1} as int8 bits
+    buf[:, 28:28 + 2 * F] = x.view(torch.uint8).view(n, 2 * F)
+    buf[:, 28 + 2 * F:28 + 2 * F + 4 * A] = vis.view(torch.uint8).view(n, 4 * A)
+    del x, vis, xpool, edges, pick
+    torch.cuda.synchronize()
+    out = {"metric": "train_data_rows_per_sec", "unit": "rows/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
+           "config": {"workload": "%dx%d, %d packed replay rows in HBM (%d B/row), position pool %d" % (rows, cols, n, rb, pool)}}
+    for avg in (False, True):
+        e.dataset_begin()
+        e.dataset_add_rows(buf)
+        e.dataset_finish(avg)  # warm-up (allocations)
+        t0 = time.perf_counter()
+        e.dataset_begin()
+        e.dataset_add_rows(buf)
+        m = e.dataset_finish(avg)
+        dt = time.perf_counter() - t0
+        # algorithmic bytes: read the packed row, write x + pi + z of the dataset row
+        byts = n * rb + m * (2 * F + 4 * A + 4)
+        out["build_pos_average" if avg else "build_raw"] = {"rows_in": n, "rows_out": m, "seconds": dt, "rows_per_sec": n / dt,
+                                                             "GBps_algorithmic": byts / dt / 1e9}
+    m = out["build_pos_average"]["rows_out"]
+    rs = np.random.RandomState(0)
+    res = {}
+    for B in (4096, 262144):
+        idx = rs.randint(0, m, size=B).astype(np.int32)
+        e.dataset_batch(idx, 5)
+        reps = 50 if B <= 4096 else 10
+        t0 = time.perf_counter()
+        for r in range(reps):
+            e.dataset_batch(idx, r & 7)
+        dt = (time.perf_counter() - t0) / reps
+        byts = B * ((2 * F + 4 * A + 4) + (4 * F + 4 * A + 4))  # read dataset row, write float32 boards + pi + z
+        res[str(B)] = {"seconds_per_batch": dt, "rows_per_sec": B / dt, "GBps_algorithmic": byts / dt / 1e9}
+    out["batch"] = res
+    big = res["262144"]
+    out["value"] = big["rows_per_sec"]
+    out["roofline"] = {"bound": "hbm", "kernel": "k_make_batch (gather + symmetry LUT, one wave per row)",
+                       "achieved": big["GBps_algorithmic"], "peak": 8000.0, "unit": "GB/s", "frac": big["GBps_algorithmic"] / 8000.0,
+                       "traffic": None, "note": "wall clock per call incl. index upload, allocation of the output tensors and the "
+                                                "stream sync that orders the batch before torch"}
+    print(json.dumps(out), flush=True)
+    e.close()
+
+
 def tower_roofline(args, m, steps, precision):
     HW = (args.board + 1) ** 2
     conv_flops = 2.0 * HW * 9 * args.channels * args.channels  # per sample per conv3x3 layer
@@ -194,6 +263,9 @@ def main():
     ap.add_argument("--full-games", type=int, default=0,
                     help="instead of timing K steps, play this many COMPLETE games from the empty board and report "
                          "games/s and expansions/game measured directly (one JSON line, metric selfplay_games_per_sec)")
+    ap.add_argument("--train-data", type=int, default=0,
+                    help="instead of the self-play step: time the training data path (dataset build + batch assembly) "
+                         "on this many synthetic replay rows in HBM (one JSON line, metric train_data_rows_per_sec)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -208,6 +280,9 @@ def main():
 
     if args.full_games > 0:
         full_games(args, rank, local_rank, world, torch)
+        return
+    if args.train_data > 0:
+        train_data_bench(args, local_rank, torch)
         return
     eng, m = run_engine(args, args.precision, args.steps, args.warmup, rank, local_rank, world, dist, torch)
     # replay all-gather at iteration end (multi-GPU): whatever finished + a fixed synthetic shard
