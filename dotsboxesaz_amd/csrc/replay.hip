@@ -25,6 +25,7 @@
 // Compiled with -ffp-contract=off (Kahan sums must not be contracted).
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <vector>
 
 #include "replay.h"
@@ -58,6 +59,7 @@ struct DevBuf {
 struct ReplayDS {
     Geo g;
     int KW = 1;           // 64-bit words of the sort key
+    int FP = 4;           // shorts per SoA x row: 3HW rounded up to 4 (8-byte aligned rows)
     int64_t n_stage = 0;  // rows staged
     int64_t n_out = 0;    // dataset rows (after pos_average)
     bool finished = false;
@@ -130,44 +132,78 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
-// one wave per selected row
+// One wave per selected row, rows taken in a block-uniform loop.  The 8-byte-aligned packed row is
+// read with 8-byte lane loads into a per-wave LDS image; fields are then picked from LDS at their
+// natural (2-byte) alignment and leave as 8-byte stores (x rows are padded to FP = F rounded up to 4
+// shorts so that every SoA row starts 8-byte aligned).
 __global__ void __launch_bounds__(256) k_ds_stage(const unsigned char *__restrict__ rows, int row_bytes, int64_t n_rows,
-                                                  const int32_t *__restrict__ sel, int64_t n_sel, int64_t base, int F, int A,
-                                                  int HW, int KW, int16_t *st_x, int32_t *st_vis, int8_t *st_z,
+                                                  const int32_t *__restrict__ sel, int64_t n_sel, int64_t base, int F, int FP, int A,
+                                                  int KW, int16_t *st_x, int32_t *st_vis, int8_t *st_z,
                                                   unsigned long long *st_key, int32_t *errflag)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= n_sel) return;
-    const int64_t r = sel ? (int64_t)sel[i] : i;
-    if (r < 0 || r >= n_rows) { // wave-uniform
-        if (lane == 0) atomicOr(errflag, 2);
-        return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int rbp = (row_bytes + 15) & ~15;
+    unsigned char *img = lds_raw + (size_t)wave * rbp;
+    const int units = row_bytes >> 3;
+    const int64_t stride = (int64_t)gridDim.x * nw;
+    const int64_t iters = (n_sel + stride - 1) / stride;
+    for (int64_t it = 0; it < iters; it++) {
+        const int64_t i = it * stride + (int64_t)blockIdx.x * nw + wave;
+        int64_t r = -1;
+        if (i < n_sel) {
+            r = sel ? (int64_t)sel[i] : i;
+            if (r < 0 || r >= n_rows) {
+                if (lane == 0) atomicOr(errflag, 2);
+                r = -1;
+            }
+        }
+        if (r >= 0) {
+            const uint2 *src = reinterpret_cast<const uint2 *>(rows + (size_t)r * row_bytes);
+            for (int u = lane; u < units; u += 64) reinterpret_cast<uint2 *>(img)[u] = src[u];
+        }
+        __syncthreads();
+        if (r >= 0) {
+            const int64_t o = base + i;
+            const short *sx = reinterpret_cast<const short *>(img + ROW_X_OFF);
+            const unsigned short *sv = reinterpret_cast<const unsigned short *>(img + ROW_X_OFF + 2 * (size_t)F);
+            const short x2 = sx[A];
+            bool bad = false;
+            for (int u = lane; u < FP / 4; u += 64) {
+                short v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int k = 4 * u + j;
+                    v[j] = k < F ? sx[k] : (short)0;
+                    if (k < A) bad |= (v[j] != 0 && v[j] != 1);
+                    else if (k < F) bad |= (v[j] != x2);
+                }
+                uint2 pk;
+                pk.x = (unsigned)(unsigned short)v[0] | ((unsigned)(unsigned short)v[1] << 16);
+                pk.y = (unsigned)(unsigned short)v[2] | ((unsigned)(unsigned short)v[3] << 16);
+                reinterpret_cast<uint2 *>(st_x + o * FP)[u] = pk;
+            }
+            for (int u = lane; u < A / 2; u += 64) {
+                uint2 pk;
+                pk.x = (unsigned)sv[4 * u] | ((unsigned)sv[4 * u + 1] << 16);
+                pk.y = (unsigned)sv[4 * u + 2] | ((unsigned)sv[4 * u + 3] << 16);
+                reinterpret_cast<uint2 *>(st_vis + o * A)[u] = pk;
+            }
+            if (lane == 0) st_z[o] = (int8_t)img[ROW_Z_OFF];
+            // key: bit b of [x_0 .. x_{A-1} | 16 bits of x_A + 32768, MSB first]; word w = bits 64w..64w+63, MSB first
+            const unsigned v16 = (unsigned)((int)x2 + 32768) & 0xFFFFu;
+            for (int w = 0; w < KW; w++) {
+                const int bidx = w * 64 + lane;
+                int bit = 0;
+                if (bidx < A) bit = sx[bidx] & 1;
+                else if (bidx < A + 16) bit = (v16 >> (15 - (bidx - A))) & 1;
+                const unsigned long long m = __ballot(bit);
+                if (lane == 0) st_key[o * KW + w] = __brevll(m);
+            }
+            if (__ballot(bad) && lane == 0) atomicOr(errflag, 1);
+        }
+        __syncthreads();
     }
-    const unsigned char *src = rows + (size_t)r * row_bytes;
-    const int16_t *sx = reinterpret_cast<const int16_t *>(src + ROW_X_OFF);
-    const unsigned short *sv = reinterpret_cast<const unsigned short *>(src + ROW_X_OFF + 2 * (size_t)F); // 2-byte aligned only
-    const int64_t o = base + i;
-    bool bad = false;
-    for (int k = lane; k < F; k += 64) {
-        const int16_t v = sx[k];
-        st_x[o * F + k] = v;
-        if (k < A) bad |= (v != 0 && v != 1);
-        else bad |= (v != sx[A]);
-    }
-    for (int k = lane; k < A; k += 64) st_vis[o * A + k] = (int32_t)((unsigned)sv[2 * k] | ((unsigned)sv[2 * k + 1] << 16));
-    if (lane == 0) st_z[o] = (int8_t)src[ROW_Z_OFF];
-    // key: bit b of the sequence [x_0 .. x_{A-1} | 16 bits of x_A + 32768, MSB first], word w holds bits 64w..64w+63, MSB first
-    const unsigned v16 = (unsigned)((int)sx[A] + 32768) & 0xFFFFu;
-    for (int w = 0; w < KW; w++) {
-        const int b = w * 64 + lane;
-        int bit = 0;
-        if (b < A) bit = sx[b] & 1;
-        else if (b < A + 16) bit = (v16 >> (15 - (b - A))) & 1;
-        const unsigned long long m = __ballot(bit);
-        if (lane == 0) st_key[o * KW + w] = __brevll(m);
-    }
-    if (__ballot(bad) && lane == 0) atomicOr(errflag, 1);
 }
 
 __global__ void k_iota(int32_t *p, int64_t n)
@@ -208,7 +244,7 @@ __global__ void k_ds_gstart(const int32_t *__restrict__ flag, const int32_t *__r
 template <int VPL>
 __global__ void __launch_bounds__(256) k_ds_mean(const int16_t *__restrict__ st_x, const int32_t *__restrict__ st_vis,
                                                  const int8_t *__restrict__ st_z, const int32_t *__restrict__ perm,
-                                                 const int32_t *__restrict__ gstart, int64_t n_groups, int F, int A,
+                                                 const int32_t *__restrict__ gstart, int64_t n_groups, int FP, int A,
                                                  int16_t *ds_x, float *ds_pi, float *ds_z)
 {
     const int lane = threadIdx.x & 63;
@@ -252,29 +288,54 @@ __global__ void __launch_bounds__(256) k_ds_mean(const int16_t *__restrict__ st_
     }
     if (lane == 0) ds_z[g] = (float)(zsum / cnt);
     const int64_t r0 = perm[i0];
-    for (int k = lane; k < F; k += 64) ds_x[g * F + k] = st_x[r0 * F + k];
+    for (int u = lane; u < FP / 4; u += 64)
+        reinterpret_cast<uint2 *>(ds_x + g * FP)[u] = reinterpret_cast<const uint2 *>(st_x + r0 * FP)[u];
 }
 
-// one wave per output row
+// One wave per output row (block-uniform loop): the dataset row (x padded to FP shorts, pi) enters
+// a per-wave LDS image with 8-byte loads, the symmetry LUT sits in LDS once per block, and the
+// float32 outputs leave coalesced.
 __global__ void __launch_bounds__(256) k_make_batch(const int16_t *__restrict__ ds_x, const float *__restrict__ ds_pi,
                                                     const float *__restrict__ ds_z, const int32_t *__restrict__ idx, int n,
-                                                    int64_t n_ds, const int32_t *__restrict__ lut /* null: identity */, int F, int A,
-                                                    float *boards, float *pi, float *z, int32_t *errflag)
+                                                    int64_t n_ds, const int32_t *__restrict__ lut /* null: identity */, int F, int FP,
+                                                    int A, float *boards, float *pi, float *z, int32_t *errflag)
 {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= n) return;
-    const int64_t r = idx[i];
-    if (r < 0 || r >= n_ds) {
-        if (lane == 0) atomicOr(errflag, 2);
-        return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int *lut_s = reinterpret_cast<int *>(lds_raw);
+    const int per_wave = FP * 2 + A * 4; // both multiples of 8
+    short *xrow = reinterpret_cast<short *>(lds_raw + (size_t)A * 4 + (size_t)wave * per_wave);
+    float *prow = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(xrow) + FP * 2);
+    for (int k = threadIdx.x; k < A; k += blockDim.x) lut_s[k] = lut ? lut[k] : k;
+    const int stride = gridDim.x * nw;
+    const int iters = (n + stride - 1) / stride;
+    for (int it = 0; it < iters; it++) {
+        const int i = it * stride + blockIdx.x * nw + wave;
+        int64_t r = -1;
+        if (i < n) {
+            r = idx[i];
+            if (r < 0 || r >= n_ds) {
+                if (lane == 0) atomicOr(errflag, 2);
+                r = -1;
+            }
+        }
+        if (r >= 0) {
+            for (int u = lane; u < FP / 4; u += 64) reinterpret_cast<uint2 *>(xrow)[u] = reinterpret_cast<const uint2 *>(ds_x + r * FP)[u];
+            for (int u = lane; u < A / 2; u += 64) reinterpret_cast<uint2 *>(prow)[u] = reinterpret_cast<const uint2 *>(ds_pi + r * A)[u];
+        }
+        __syncthreads();
+        if (r >= 0) {
+            for (int k = lane; k < F; k += 64) boards[(size_t)i * F + k] = (float)xrow[k < A ? lut_s[k] : k];
+            for (int u = lane; u < A / 2; u += 64) {
+                float2 o2;
+                o2.x = prow[lut_s[2 * u]];
+                o2.y = prow[lut_s[2 * u + 1]];
+                reinterpret_cast<float2 *>(pi + (size_t)i * A)[u] = o2;
+            }
+            if (lane == 0) z[i] = ds_z[r];
+        }
+        __syncthreads();
     }
-    for (int k = lane; k < F; k += 64) {
-        const int srck = (k < A && lut) ? lut[k] : k;
-        boards[(size_t)i * F + k] = (float)ds_x[r * F + srck];
-    }
-    for (int k = lane; k < A; k += 64) pi[(size_t)i * A + k] = ds_pi[r * A + (lut ? lut[k] : k)];
-    if (lane == 0) z[i] = ds_z[r];
 }
 
 __global__ void __launch_bounds__(256) k_symmetry(const float *__restrict__ bin, const float *__restrict__ pin, int64_t n,
@@ -297,6 +358,7 @@ ReplayDS *rds_create(const Geo &g)
     ReplayDS *d = new ReplayDS();
     d->g = g;
     d->KW = (g.A + 16 + 63) / 64;
+    d->FP = (3 * g.HW + 3) & ~3;
     return d;
 }
 
@@ -336,11 +398,12 @@ int rds_add_rows(ReplayDS *d, hipStream_t s, const void *rows_dev, int64_t n_row
     if (d->finished) { err = "dataset already finished: call dbaz_dataset_begin first"; return DBAZ_ESTATE; }
     if (row_bytes != need_rb) { err = "row_bytes does not match this board's replay row"; return DBAZ_EINVAL; }
     if (n_rows < 0 || n_sel < 0 || (!rows_dev && n_rows > 0)) { err = "bad row arguments"; return DBAZ_EINVAL; }
+    if (((uintptr_t)rows_dev & 7) != 0) { err = "replay rows must be 8-byte aligned"; return DBAZ_EINVAL; }
     if (!sel_host) n_sel = n_rows;
     if (n_sel == 0) return DBAZ_OK;
     if (d->n_stage + n_sel > 0x7FFFFFF0LL) { err = "dataset too large (int32 row indices)"; return DBAZ_EINVAL; }
     const int64_t tot = d->n_stage + n_sel;
-    RCHECK(d->st_x.ensure((size_t)tot * F * 2, true, s));
+    RCHECK(d->st_x.ensure((size_t)tot * d->FP * 2, true, s));
     RCHECK(d->st_vis.ensure((size_t)tot * A * 4, true, s));
     RCHECK(d->st_z.ensure((size_t)tot, true, s));
     RCHECK(d->st_key.ensure((size_t)tot * d->KW * 8, true, s));
@@ -352,9 +415,10 @@ int rds_add_rows(ReplayDS *d, hipStream_t s, const void *rows_dev, int64_t n_row
         RCHECK(hipMemcpyAsync(d->sel.p, sel_host, (size_t)n_sel * 4, hipMemcpyHostToDevice, s));
         sel_dev = (const int32_t *)d->sel.p;
     }
-    const unsigned blocks = (unsigned)((n_sel + 3) / 4);
-    hipLaunchKernelGGL(k_ds_stage, dim3(blocks), dim3(256), 0, s, (const unsigned char *)rows_dev, row_bytes, n_rows, sel_dev, n_sel,
-                       d->n_stage, F, A, g.HW, d->KW, (int16_t *)d->st_x.p, (int32_t *)d->st_vis.p, (int8_t *)d->st_z.p,
+    const unsigned blocks = (unsigned)std::min<int64_t>((n_sel + 3) / 4, 256 * 32);
+    const size_t lds_stage = 4 * (size_t)((row_bytes + 15) & ~15);
+    hipLaunchKernelGGL(k_ds_stage, dim3(blocks), dim3(256), lds_stage, s, (const unsigned char *)rows_dev, row_bytes, n_rows, sel_dev, n_sel,
+                       d->n_stage, F, d->FP, A, d->KW, (int16_t *)d->st_x.p, (int32_t *)d->st_vis.p, (int8_t *)d->st_z.p,
                        (unsigned long long *)d->st_key.p, (int32_t *)d->err.p);
     RCHECK(hipGetLastError());
     int flag = 0;
@@ -369,7 +433,7 @@ int rds_add_rows(ReplayDS *d, hipStream_t s, const void *rows_dev, int64_t n_row
 int rds_finish(ReplayDS *d, hipStream_t s, int pos_average, const int32_t *order_host, int64_t *n_out, std::string &err)
 {
     const Geo &g = d->g;
-    const int F = 3 * g.HW, A = g.A, KW = d->KW;
+    const int A = g.A, KW = d->KW;
     const int64_t n = d->n_stage;
     if (d->finished) { err = "dataset already finished"; return DBAZ_ESTATE; }
     d->n_out = 0;
@@ -425,14 +489,14 @@ int rds_finish(ReplayDS *d, hipStream_t s, int pos_average, const int32_t *order
     int32_t m = 0;
     RCHECK(hipMemcpyAsync(&m, (const int32_t *)d->gid.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
     RCHECK(hipStreamSynchronize(s));
-    RCHECK(d->ds_x.ensure((size_t)m * F * 2, false, s));
+    RCHECK(d->ds_x.ensure((size_t)m * d->FP * 2, false, s));
     RCHECK(d->ds_pi.ensure((size_t)m * A * 4, false, s));
     RCHECK(d->ds_z.ensure((size_t)m * 4, false, s));
     const unsigned gb = (unsigned)((m + 3) / 4);
     const int vpl = (A + 63) / 64;
 #define MEAN(V)                                                                                                              \
     hipLaunchKernelGGL(k_ds_mean<V>, dim3(gb), dim3(256), 0, s, (const int16_t *)d->st_x.p, (const int32_t *)d->st_vis.p,     \
-                       (const int8_t *)d->st_z.p, (const int32_t *)d->perm.p, (const int32_t *)d->gstart.p, (int64_t)m, F, A, \
+                       (const int8_t *)d->st_z.p, (const int32_t *)d->perm.p, (const int32_t *)d->gstart.p, (int64_t)m, d->FP, A, \
                        (int16_t *)d->ds_x.p, (float *)d->ds_pi.p, (float *)d->ds_z.p)
     switch (vpl) {
     case 1: MEAN(1); break;
@@ -456,7 +520,7 @@ int rds_fetch(ReplayDS *d, hipStream_t s, int16_t *x, float *pi, float *z, std::
     const int F = 3 * d->g.HW, A = d->g.A;
     const int64_t m = d->n_out;
     if (m == 0) return DBAZ_OK;
-    if (x) RCHECK(hipMemcpyAsync(x, d->ds_x.p, (size_t)m * F * 2, hipMemcpyDeviceToHost, s));
+    if (x) RCHECK(hipMemcpy2DAsync(x, (size_t)F * 2, d->ds_x.p, (size_t)d->FP * 2, (size_t)F * 2, (size_t)m, hipMemcpyDeviceToHost, s));
     if (pi) RCHECK(hipMemcpyAsync(pi, d->ds_pi.p, (size_t)m * A * 4, hipMemcpyDeviceToHost, s));
     if (z) RCHECK(hipMemcpyAsync(z, d->ds_z.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
     RCHECK(hipStreamSynchronize(s));
@@ -479,8 +543,10 @@ int rds_batch(ReplayDS *d, hipStream_t s, const int32_t *idx_host, int n, int sy
     RCHECK(hipMemsetAsync(d->err.p, 0, 16, s));
     RCHECK(hipMemcpyAsync(d->idx.p, idx_host, (size_t)n * 4, hipMemcpyHostToDevice, s));
     const int32_t *lut = sym ? (const int32_t *)d->lut.p + (size_t)sym * A : nullptr;
-    hipLaunchKernelGGL(k_make_batch, dim3((n + 3) / 4), dim3(256), 0, s, (const int16_t *)d->ds_x.p, (const float *)d->ds_pi.p,
-                       (const float *)d->ds_z.p, (const int32_t *)d->idx.p, n, d->n_out, lut, F, A, boards_dev, pi_dev, z_dev,
+    const size_t lds_batch = (size_t)A * 4 + 4 * ((size_t)d->FP * 2 + (size_t)A * 4);
+    hipLaunchKernelGGL(k_make_batch, dim3(std::min((n + 3) / 4, 256 * 32)), dim3(256), lds_batch, s, (const int16_t *)d->ds_x.p,
+                       (const float *)d->ds_pi.p, (const float *)d->ds_z.p, (const int32_t *)d->idx.p, n, d->n_out, lut, F, d->FP, A,
+                       boards_dev, pi_dev, z_dev,
                        (int32_t *)d->err.p);
     RCHECK(hipGetLastError());
     int flag = 0;
