@@ -61,14 +61,34 @@ def test_golden_case(name):
 def test_many_slots_vs_oracle(rows, cols, n_slots, sims, kind):
     """Every slot searches a different position; three searches with tree reuse, noise on the
     second one; root arrays compared with the C oracle slot by slot."""
+    _run_vs_oracle(rows, cols, n_slots, sims, kind, (1.25, 19652), True, n_slots + sims)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_configuration_sweep(seed):
+    """Seeded sweep over board shapes (1x1 .. 9x9, non-square included), slot counts, read counts,
+    cpuct constants, evaluator formula and fresh-vs-reused trees."""
+    rng = np.random.RandomState(1000 + seed)
+    rows, cols = int(rng.randint(1, 10)), int(rng.randint(1, 10))
+    if seed == 0:
+        rows, cols = 1, 1
+    if seed == 1:
+        rows, cols = 9, 9
+    n_slots = int(rng.randint(3, 40))
+    sims = int(rng.randint(4, 140))
+    cpuct = (float(rng.choice([0.5, 1.25, 2.0, 4.0])), float(rng.choice([100.0, 19652.0])))
+    _run_vs_oracle(rows, cols, n_slots, sims, int(rng.randint(0, 2)), cpuct, bool(rng.randint(0, 2)), seed)
+
+
+def _run_vs_oracle(rows, cols, n_slots, sims, kind, cpuct, reuse, seed):
     from dotsboxesaz_amd.engine import Engine
     d = O.dims(rows, cols)
-    rng = np.random.RandomState(n_slots + sims)
+    rng = np.random.RandomState(seed)
     starts = []
     for s in range(n_slots):
         st = O.new_state(d)
         mv = []
-        for _ in range(rng.randint(0, d.A // 3)):
+        for _ in range(rng.randint(0, max(1, d.A // 3))):
             legal = np.nonzero(O.valid_moves(d, st))[0]
             m = int(legal[rng.randint(len(legal))])
             tmp = st.copy()
@@ -85,12 +105,13 @@ def test_many_slots_vs_oracle(rows, cols, n_slots, sims, kind):
     reads = rng.randint(1, sims + 1, size=n_slots).astype(np.int32)
     for rnd, (alpha, coeff) in enumerate([(0.0, 0.0), (0.8, 0.25), (0.0, 0.0)]):
         noise = rng.dirichlet(np.full(d.A, 0.8), size=n_slots) if alpha > 0 else None
-        e.set_search_params((1.25, 19652), (alpha, coeff))
+        e.set_search_params(cpuct, (alpha, coeff))
         e.search(reads, noise)
         r = e.roots()
         moves = np.zeros(n_slots, np.int32)
         for s in range(n_slots):
-            vis = trees[s].search(int(reads[s]), ev, dirichlet=(alpha, coeff), noise=None if noise is None else noise[s])
+            vis = trees[s].search(int(reads[s]), ev, cpuct=cpuct, dirichlet=(alpha, coeff),
+                                  noise=None if noise is None else noise[s])
             pri, tv, nv, pc = trees[s].root_arrays()
             assert np.array_equal(r["visits"][s], vis), (rnd, s)
             assert np.array_equal(r["total_value"][s].view(np.uint32), tv.view(np.uint32)), (rnd, s)
@@ -110,8 +131,8 @@ def test_many_slots_vs_oracle(rows, cols, n_slots, sims, kind):
             if O.get_result(tmp) is not None:
                 moves[s] = -1  # do not walk into a terminal root (nothing to search there)
             else:
-                trees[s].advance(int(moves[s]), True)
-        e.advance(moves, True)
+                trees[s].advance(int(moves[s]), reuse)
+        e.advance(moves, reuse)
     e.close()
 
 
