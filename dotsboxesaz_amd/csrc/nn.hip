@@ -780,6 +780,40 @@ struct HeadArgs {
     int value_direct; // SimpleNN: value = tanh(value_fc(x)), no hidden layer
 };
 
+// K is split over the 4 waves (wave w owns the 16-wide k chunks kc = w, w+4, ...).  Nothing is staged:
+// a lane reads its activation fragment (16 B of sample row lane&15) and its weight fragments straight
+// from global memory / L2 in MFMA operand layout, three chunks ahead of the MFMAs (a register ring
+// of depth 3 hides the L2 latency that a staged, one-deep version paid once per chunk); the
+// policy tiles and the value tile share one K loop (8 output tiles per pass).  The four partial
+// sums meet in LDS and are added in wave order, so a sample's result does not depend on the
+// batch it is evaluated in.  Rows >= ns compute on a clamped (valid) row and are discarded.
+#define HEAD_JG 8
+struct HeadFrag {
+    f32x4 a[HEAD_JG];
+    f32x4 b0, b1;
+};
+
+__device__ __forceinline__ void head_load(HeadFrag &f, const f32x4 *wfc4, const float *row0, const float *row1, int KC, int kc,
+                                          int jg, int nj, int lane, int gq)
+{
+#pragma unroll
+    for (int j = 0; j < HEAD_JG; j++)
+        if (j < nj) f.a[j] = wfc4[((size_t)(jg + j) * KC + kc) * 64 + lane];
+    f.b0 = *reinterpret_cast<const f32x4 *>(row0 + kc * 16 + gq * 4);
+    f.b1 = *reinterpret_cast<const f32x4 *>(row1 + kc * 16 + gq * 4);
+}
+
+__device__ __forceinline__ void head_mfma(f32x4 (&acc)[HEAD_JG], const HeadFrag &f, int jg, int nj, int ntp)
+{
+#pragma unroll
+    for (int j = 0; j < HEAD_JG; j++)
+        if (j < nj) {
+            const f32x4 b = (jg + j < ntp) ? f.b0 : f.b1; // wave-uniform select
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[j][e], b[e], acc[j], 0, 0, 0);
+        }
+}
+
 __global__ void __launch_bounds__(256) k_head_fc(Geo g, HeadArgs h)
 {
     extern __shared__ __attribute__((aligned(16))) float ldsf[];
@@ -788,50 +822,47 @@ __global__ void __launch_bounds__(256) k_head_fc(Geo g, HeadArgs h)
     if (j0 >= n) return;
     const int ns = min(16, n - j0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int RS = h.RS4 * 4, KP = h.KP, K = h.K, A = g.A;
+    const int KP = h.KP, K = h.K, A = g.A;
     const int NJ = h.ntp + h.ntv, LGS = NJ * 16 + 1;
-    float *act = ldsf;               // [16][RS]: one head's activations at a time
-    float *lg = ldsf + 16 * RS;      // [16][LGS]
+    float *part = ldsf;                        // [4 waves][16][NJ*16] partial sums
+    float *lg = ldsf + 4 * 16 * NJ * 16;       // [16][LGS]
     const int jrow = lane & 15, gq = lane >> 4;
-    const f32x4 *act4 = reinterpret_cast<const f32x4 *>(act);
     const int KC = KP / 16;
-    for (int hd = 0; hd < 2; hd++) {
-        __syncthreads();
-        for (int i = tid; i < 16 * KP; i += 256) {
-            int sidx = i / KP, k = i - sidx * KP;
-            float v = 0.0f;
-            if (sidx < ns && k < K) v = h.hact[((size_t)(j0 + sidx) * 2 + hd) * K + k];
-            act[sidx * RS + k] = v;
-        }
-        __syncthreads();
-        const int jb = hd == 0 ? 0 : h.ntp, je = hd == 0 ? h.ntp : NJ;
-        for (int job = jb + wave; job < je; job += 4) {
-            const f32x4 *wb = reinterpret_cast<const f32x4 *>(h.wfc) + (size_t)job * KC * 64 + lane;
-            const f32x4 *bb = act4 + jrow * h.RS4 + gq;
-            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-            int kc = 0;
-            for (; kc + 1 < KC; kc += 2) {
-                const f32x4 a0 = wb[(size_t)kc * 64], a1 = wb[(size_t)(kc + 1) * 64];
-                const f32x4 b0 = bb[kc * 4], b1 = bb[(kc + 1) * 4];
+    const f32x4 *wfc4 = reinterpret_cast<const f32x4 *>(h.wfc);
+    const float *row0 = h.hact + ((size_t)(j0 + min(jrow, ns - 1)) * 2 + 0) * K;
+    const float *row1 = row0 + K;
+    const int nk = wave < KC ? (KC - wave + 3) / 4 : 0; // chunks of this wave
+    for (int jg = 0; jg < NJ; jg += HEAD_JG) {
+        const int nj = min(HEAD_JG, NJ - jg);
+        f32x4 acc[HEAD_JG];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc1, 0, 0, 0);
-                }
+        for (int j = 0; j < HEAD_JG; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        HeadFrag f0, f1, f2;
+        if (0 < nk) head_load(f0, wfc4, row0, row1, KC, wave, jg, nj, lane, gq);
+        if (1 < nk) head_load(f1, wfc4, row0, row1, KC, wave + 4, jg, nj, lane, gq);
+        for (int i = 0; i < nk; i += 3) {
+            if (i + 2 < nk) head_load(f2, wfc4, row0, row1, KC, wave + 4 * (i + 2), jg, nj, lane, gq);
+            head_mfma(acc, f0, jg, nj, h.ntp);
+            if (i + 1 < nk) {
+                if (i + 3 < nk) head_load(f0, wfc4, row0, row1, KC, wave + 4 * (i + 3), jg, nj, lane, gq);
+                head_mfma(acc, f1, jg, nj, h.ntp);
             }
-            if (kc < KC) {
-                const f32x4 a0 = wb[(size_t)kc * 64];
-                const f32x4 b0 = bb[kc * 4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc0, 0, 0, 0);
-            }
-            const f32x4 acc = acc0 + acc1;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int o = job * 16 + gq * 4 + r;
-                lg[jrow * LGS + o] = acc[r] + h.bfc[o];
+            if (i + 2 < nk) {
+                if (i + 4 < nk) head_load(f1, wfc4, row0, row1, KC, wave + 4 * (i + 4), jg, nj, lane, gq);
+                head_mfma(acc, f2, jg, nj, h.ntp);
             }
         }
+        float *pw = part + ((size_t)wave * 16 + jrow) * (NJ * 16);
+#pragma unroll
+        for (int j = 0; j < HEAD_JG; j++)
+            if (j < nj) *reinterpret_cast<f32x4 *>(pw + (jg + j) * 16 + gq * 4) = acc[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * NJ * 16; i += 256) {
+        const int row = i / (NJ * 16), o = i - row * (NJ * 16);
+        const float *p0 = part + i;
+        const int st = 16 * NJ * 16;
+        lg[row * LGS + o] = ((p0[0] + p0[st]) + (p0[2 * st] + p0[3 * st])) + h.bfc[o];
     }
     __syncthreads();
     for (int sidx = wave; sidx < ns; sidx += 4) {
@@ -1168,11 +1199,12 @@ static int commit_simplenn(NNState *nn, std::string &err)
         nn->wv1 = nn_upload(nn, one);
         nn->bv1 = nn_upload(nn, one);
         nn->KP = K; nn->ntp = ntp; nn->ntv = ntv; nn->RS4 = dense_rs4(K);
-        nn->fc_lds = ((size_t)16 * nn->RS4 * 4 + (size_t)16 * (NJ * 16 + 1)) * 4;
+        nn->fc_lds = ((size_t)4 * 16 * NJ * 16 + (size_t)16 * (NJ * 16 + 1)) * 4;
     }
     nn->sn_flat = nn_alloc<float>(nn, (size_t)nn->max_batch * 1024);
     nn->sn_h1 = nn_alloc<float>(nn, (size_t)nn->max_batch * 512);
-    nn->hact = nn_alloc<float>(nn, (size_t)nn->max_batch * 2 * 256);
+    nn->hact = nn_alloc<float>(nn, (size_t)nn->max_batch * 2 * 256 + 16);
+    if (nn->hact) (void)hipMemset(nn->hact, 0, ((size_t)nn->max_batch * 2 * 256 + 16) * sizeof(float));
     if (!nn->sn_flat || !nn->sn_h1 || !nn->hact || !nn->wfc) { err = "hipMalloc failed (SimpleNN buffers)"; return DBAZ_EDEVICE; }
     // LDS: two images of S*16 rows x 264 dwords (+ zero regions); S = 4 -> 141 KB
     const size_t s4 = (C + 8) / 4;
@@ -1290,13 +1322,16 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         int rs4 = KP / 4;
         rs4 = ((rs4 + 15) / 16) * 16 + 2; // = 2 mod 16 float4 units
         nn->RS4 = rs4;
-        nn->fc_lds = ((size_t)16 * rs4 * 4 + (size_t)16 * (NJ * 16 + 1)) * 4;
+        nn->fc_lds = ((size_t)4 * 16 * NJ * 16 + (size_t)16 * (NJ * 16 + 1)) * 4;
         if (nn->fc_lds > 158 * 1024) { err = "head FC tile does not fit LDS"; return DBAZ_EINVAL; }
         if (hipFuncSetAttribute((const void *)k_head_fc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->fc_lds) != hipSuccess) {
             err = "hipFuncSetAttribute(k_head_fc) failed"; return DBAZ_EDEVICE;
         }
     }
-    nn->hact = nn_alloc<float>(nn, (size_t)nn->max_batch * 2 * K);
+    // k_head_fc reads whole 16-float chunks: up to 15 floats past a row's K when K % 16 != 0 (their weights are
+    // zero, so the values only have to be finite): slack at the end, everything zero-initialised
+    nn->hact = nn_alloc<float>(nn, (size_t)nn->max_batch * 2 * K + 16);
+    if (nn->hact) (void)hipMemset(nn->hact, 0, ((size_t)nn->max_batch * 2 * K + 16) * sizeof(float));
     if (!nn->hact || !nn->wv1 || !nn->w0) { err = "hipMalloc failed (network buffers)"; return DBAZ_EDEVICE; }
     // conv workgroup geometry: S whole samples, NT position tiles of 16 rows (<= MAXT)
     const size_t lds_budget = 158 * 1024; // of 160 KiB: two ping-pong activation images
