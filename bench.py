@@ -79,7 +79,8 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
     from dotsboxesaz_amd import nn as dnn
     rows = cols = args.board
     eng = Engine(rows, cols, args.slots, mcts_num_read=args.sims, noise=(0.8, 0.25), reuse_tree=True,
-                 evaluator=args.evaluator, seed=1000 + rank, device=local_rank, nn_precision=precision)
+                 evaluator=args.evaluator, seed=1000 + rank, device=local_rank, nn_precision=precision,
+                 nodes_per_slot=args.nodes_per_slot)
     if args.evaluator == "resnet":
         torch.manual_seed(0)
         model = dnn.ResNetZero(dnn.resnet_params(rows, cols, args.channels, args.blocks))
@@ -257,6 +258,7 @@ def main():
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "simplenn", "formula", "uniform"])
     ap.add_argument("--precision", type=int, default=1,
                     help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default)")
+    ap.add_argument("--nodes-per-slot", type=int, default=0, help="tree node pool per game (0 = engine default 10*(sims+2))")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-side-run", action="store_true")

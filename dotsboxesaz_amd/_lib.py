@@ -66,6 +66,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `python -m dotsboxesaz_amd.build` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # A process that also uses torch must load torch's bundled HIP runtime BEFORE this library pulls in
+    # the system one: in the other order torch's later initialisation finds "No HIP GPUs" (two runtimes
+    # competing for the device; measured on ROCm 7.2 + torch 2.10/rocm7.0).  The library itself has no
+    # torch dependency -- a process without torch simply runs on the system runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.dbaz_last_error.argtypes = [vp]

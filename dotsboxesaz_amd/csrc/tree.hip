@@ -359,22 +359,86 @@ __device__ __forceinline__ bool cand_beats(double xa, int ia, bool ha, double xb
     return xa > xb || (xa == xb && ia < ib);
 }
 
-__global__ void __launch_bounds__(WAVE) k_select(Geo g, SearchCfg cfg, TreeBufs B)
+// The four rows of a node (this lane's children i = lane + 64 j) and its meta block are fetched
+// together -- the descent then costs ONE dependent memory round trip per tree level (the next
+// node's rows are requested the moment the child index is known, which itself comes out of the
+// prefetched C row by shuffle) instead of four (rows in two dependent strides, C[best], meta).
+#ifdef DBAZ_STAMP
+// diagnostic build only (tools/stamp_select.sh): cycle stamps of a k_select wave, printed for a few slots
+#define TSTAMP(var) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define TSTAMP(var) do { } while (0)
+#endif
+
+// pb_c's N-dependent factor  log((N + base + 1) / base) + cpuct  and  sqrt(N)  (mcts.py:92-94) from the
+// host-libm tables.  N is wave-uniform: the loads are unconditional scalar loads (clamped index) so that
+// they can be in flight together with the node's rows; beyond the table the device computes the terms
+// (never reached with the default table sizing).
+__device__ __forceinline__ void select_tab(const SearchCfg &cfg, const TreeBufs &B, int N, double &pbc, double &sq)
 {
-    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int i = min(N, cfg.table_n - 1);
+    pbc = B.pbc_table[i];
+    sq = B.sqrt_table[i];
+}
+__device__ __forceinline__ void select_tab_fix(const SearchCfg &cfg, int N, double &pbc, double &sq)
+{
+    if (N >= cfg.table_n) {
+        pbc = log(((double)N + cfg.cpuct_base + 1.0) / cfg.cpuct_base) + cfg.cpuct;
+        sq = sqrt((double)N);
+    }
+}
+
+template <int NPL>
+struct NodeRows {
+    float P[NPL], W[NPL];
+    uint32_t NS[NPL];
+    int32_t C[NPL];
+};
+
+template <int NPL>
+__device__ __forceinline__ void load_rows(NodeRows<NPL> &r, uint32_t *pool, const Geo &g, int idx, int lane)
+{
+    const uint32_t *nd = node_ptr(pool, g, idx) + META_DW;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int i = lane + WAVE * j;
+        const bool ok = i < g.A;
+        r.P[j] = ok ? reinterpret_cast<const float *>(nd)[i] : 0.0f;
+        r.W[j] = ok ? reinterpret_cast<const float *>(nd + g.AS)[i] : 0.0f;
+        r.NS[j] = ok ? nd[2 * g.AS + i] : 0u;
+        r.C[j] = ok ? reinterpret_cast<const int32_t *>(nd + 3 * g.AS)[i] : -1;
+    }
+}
+
+#define SELECT_WAVES 16 // games per workgroup (one wave each)
+// returns the model (0 / 1) whose network must evaluate this game's leaf, or -1
+template <int NPL>
+__device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, int lane)
+{
     Slot *S = B.slots + slot;
     const int phase = S->phase;
     if (phase != PH_EXPAND_ROOT && phase != PH_SIMS)
-        return;
+        return -1;
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
     PathEnt *path = B.path + (size_t)slot * g.dmax;
     const double *rprior = B.root_prior + (size_t)slot * g.AS;
     const int A = g.A;
 
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts_mem = 0, ts_tab = 0, ts_ucb = 0, ts_arg = 0, tq0 = 0, tq1 = 0;
+    (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts_mem; (void)ts_tab; (void)ts_ucb; (void)ts_arg; (void)tq0; (void)tq1;
+    TSTAMP(ts0);
     int cur = 0, depth = 0, in_move = -1;
     int n_nodes = S->n_nodes;
     int Nself = S->root_N;
     NodeMeta m = load_meta(pool, g, 0);
+    NodeRows<NPL> R;
+    load_rows<NPL>(R, pool, g, 0, lane);
+    double pbc_cur, sq_cur;
+    select_tab(cfg, B, Nself, pbc_cur, sq_cur);
+    select_tab_fix(cfg, Nself, pbc_cur, sq_cur);
+    double rp[NPL]; // float64 root priors (root_prep), used for the root level only
+#pragma unroll
+    for (int j = 0; j < NPL; j++) rp[j] = (lane + WAVE * j < A) ? rprior[lane + WAVE * j] : 0.0;
     in_move = m.move;
     // match play (self_play.py:59,237-239): the player to move at the ROOT selects the model for the
     // whole search of this move; odd games swap the seats (the reference shuffles them by worker pid)
@@ -383,58 +447,95 @@ __global__ void __launch_bounds__(WAVE) k_select(Geo g, SearchCfg cfg, TreeBufs 
         if (lane == 0)
             S->root_W = S->root_W - 1.0f; // current.total_value -= VIRTUAL_LOSS (root slot)
     }
-    int err = 0;
+    int err = 0, need_eval = -1;
+    TSTAMP(ts1);
     while ((m.flags & NF_EXPANDED) && !(m.flags & NF_TERMINAL)) {
         uint32_t *nd = node_ptr(pool, g, cur);
-        const float *Prow = reinterpret_cast<const float *>(nd + META_DW);
         float *Wrow = reinterpret_cast<float *>(nd + META_DW + g.AS);
         uint32_t *NSrow = nd + META_DW + 2 * g.AS;
         int32_t *Crow = reinterpret_cast<int32_t *>(nd + META_DW + 3 * g.AS);
-        // children_ucb_score, mcts.py:91-99 (float64 throughout)
-        double pbc0, sq;
-        if (Nself < cfg.table_n) {
-            pbc0 = B.pbc_table[Nself];
-            sq = B.sqrt_table[Nself];
-        } else {
-            pbc0 = log(((double)Nself + cfg.cpuct_base + 1.0) / cfg.cpuct_base) + cfg.cpuct;
-            sq = sqrt((double)Nself);
-        }
+        // children_ucb_score, mcts.py:91-99 (float64 throughout); the N-dependent terms were requested
+        // together with this node's rows (select_tab)
+        TSTAMP(tq0);
+        const double pbc0 = pbc_cur, sq = sq_cur;
+#ifdef DBAZ_STAMP
+        asm volatile("" ::"v"(pbc0), "v"(sq));
+        TSTAMP(tq1); ts_tab += tq1 - tq0;
+#endif
+        // Branch-free scan of this lane's children (word j of the played / sentinel masks holds child lane + 64 j)
+        const uint64_t ew[4] = {m.st.e0, m.st.e1, m.st.e2, m.st.e3};
         double bx = 0.0;
-        int bi = 0x7fffffff;
+        int bj = 0;
         float bw = 0.0f;
         uint32_t bns = 0;
+        int bc = -1;
         bool have = false;
-        for (int i = lane; i < A; i += WAVE) {
-            double P = (cur == 0) ? rprior[i] : (double)Prow[i];
-            float w = Wrow[i];
-            uint32_t ns = NSrow[i];
-            int n = (int)(ns & NS_MASK);
-            double sgn = (ns & NS_SAME) ? 1.0 : -1.0;
-            double t = sq / (double)(n + 1);
-            double pb_c = pbc0 * t;
-            double prior_score = pb_c * P;
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const int i = lane + WAVE * j;
+            const bool in = i < A;
+            const double P = (cur == 0) ? rp[j] : (double)R.P[j];
+            const float w = R.W[j];
+            const uint32_t ns = R.NS[j];
+            const int n = (int)(ns & NS_MASK);
+            const double sgn = (ns & NS_SAME) ? 1.0 : -1.0;
+            const double t = sq / (double)(n + 1);
+            const double pb_c = pbc0 * t;
+            const double prior_score = pb_c * P;
             double value_score = (double)w / (double)(1 + n);
             value_score = value_score * sgn;
-            double score = prior_score + value_score;
-            double inval = gs_valid(g, m.st, i) ? 0.0 : 1.0;
-            double x = -1e12 * inval + score; // best_child, mcts.py:101-103
-            bool take;
-            if (!have) take = true;
-            else if (bx != bx) take = false;
-            else take = !(x <= bx);
-            if (take) { bx = x; bi = i; bw = w; bns = ns; have = true; }
+            const double score = prior_score + value_score;
+            const bool valid = in && !(((ew[j] | g.sentinel[j]) >> lane) & 1ull);
+            const double inval = valid ? 0.0 : 1.0;
+            const double x = -1e12 * inval + score; // best_child, mcts.py:101-103
+            // numpy argmax order inside the lane: first maximum, a NaN already held wins
+            const bool take = in && (!have || (bx == bx && !(x <= bx)));
+            bx = take ? x : bx;
+            bj = take ? j : bj;
+            bw = take ? w : bw;
+            bns = take ? ns : bns;
+            bc = take ? R.C[j] : bc;
+            have = have || take;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            double ox = __shfl_xor(bx, o);
-            int oi = __shfl_xor(bi, o);
-            int oh = __shfl_xor((int)have, o);
-            if (cand_beats(ox, oi, oh != 0, bx, bi, have)) { bx = ox; bi = oi; have = true; }
+#ifdef DBAZ_STAMP
+        asm volatile("" ::"v"(bx), "v"(bj));
+        TSTAMP(tq0); ts_ucb += tq0 - tq1;
+#endif
+        int bi;
+        if (__ballot(have && bx != bx) == 0ull) {
+            // no NaN anywhere (always, in practice): wave maximum, then the lowest child index that attains it
+            double mx = have ? bx : -INFINITY;
+            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+            bi = -1;
+#pragma unroll
+            for (int j = 0; j < NPL; j++) {
+                const unsigned long long mk = __ballot(have && bx == mx && bj == j);
+                if (bi < 0 && mk != 0ull) bi = WAVE * j + (__ffsll((long long)mk) - 1);
+            }
+        } else {
+            // numpy's argmax with NaNs (the first NaN wins): generic butterfly
+            bi = have ? lane + WAVE * bj : 0x7fffffff;
+            double rx = bx;
+            bool rh = have;
+            for (int o = 32; o > 0; o >>= 1) {
+                double ox = __shfl_xor(rx, o);
+                int oi = __shfl_xor(bi, o);
+                int oh = __shfl_xor((int)rh, o);
+                if (cand_beats(ox, oi, oh != 0, rx, bi, rh)) { rx = ox; bi = oi; rh = true; }
+            }
         }
+#ifdef DBAZ_STAMP
+        asm volatile("" ::"v"(bi));
+        TSTAMP(tq1); ts_arg += tq1 - tq0;
+#endif
+        // the lane that owns child bi holds it as ITS running best (lanes scan their children in index order and
+        // the wave-wide winner is some lane's own best), so its bw / bns / bc are the winner's W, N|sign and C
+        // bi and everything read from its owner lane are wave-uniform: say so (scalar branches and loads below)
+        bi = __builtin_amdgcn_readfirstlane(bi);
         const int owner = bi & (WAVE - 1);
-        bw = __shfl(bw, owner);
-        bns = __shfl(bns, owner);
-
-        int child = Crow[bi];
+        bw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bw), owner));
+        bns = (uint32_t)__builtin_amdgcn_readlane((int)bns, owner);
+        int child = __builtin_amdgcn_readlane(bc, owner);
         if (lane == 0) {
             PathEnt pe;
             pe.node = cur; pe.move_in = (int16_t)in_move; pe.to_play = (int16_t)m.st.to_play;
@@ -462,17 +563,35 @@ __global__ void __launch_bounds__(WAVE) k_select(Geo g, SearchCfg cfg, TreeBufs 
             cur = child; in_move = bi; m = cm;
             break;
         }
+#ifdef DBAZ_STAMP
+        unsigned long long tl0, tl1;
+        TSTAMP(tl0); // includes the drain of this level's stores (path entry)
+#endif
+        // everything the next level needs is requested at once: the child's pb_c / sqrt terms (its visit count is
+        // already known from this node's N row), its meta block and its four rows
+        const int nchild = (int)(bns & NS_MASK);
+        double pbc_nx, sq_nx;
+        select_tab(cfg, B, nchild, pbc_nx, sq_nx);
         NodeMeta cm = load_meta(pool, g, child);
+        load_rows<NPL>(R, pool, g, child, lane); // rows of an unexpanded node are ignored
+        select_tab_fix(cfg, nchild, pbc_nx, sq_nx);
+#ifdef DBAZ_STAMP
+        TSTAMP(tl1);
+        ts_mem += tl1 - tl0;
+#endif
         if ((cm.flags & NF_EXPANDED) && !(cm.flags & NF_TERMINAL)) {
             if (lane == owner)
                 Wrow[bi] = bw - 1.0f; // VIRTUAL_LOSS on the node being left next iteration
-            Nself = (int)(bns & NS_MASK);
+            Nself = nchild;
+            pbc_cur = pbc_nx;
+            sq_cur = sq_nx;
         }
         cur = child; in_move = bi; m = cm;
     }
+    TSTAMP(ts2);
     if (err) {
         if (lane == 0) { S->error = err; S->phase = PH_ERROR; }
-        return;
+        return -1;
     }
     if (lane == 0) {
         PathEnt pe;
@@ -493,11 +612,36 @@ __global__ void __launch_bounds__(WAVE) k_select(Geo g, SearchCfg cfg, TreeBufs 
         for (int i = lane; i < 3 * g.HW; i += WAVE)
             f[i] = (float)gs_feature(g, m.st, i);
         const int ev = model ? cfg.evaluator2 : cfg.evaluator;
-        if (lane == 0 && (ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN)) {
-            int j = atomicAdd(B.n_eval + model, 1);
-            (model ? B.eval_list2 : B.eval_list)[j] = slot;
-        }
+        if (ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN) need_eval = model;
     }
+#ifdef DBAZ_STAMP
+    TSTAMP(ts3);
+    if (lane == 0 && (slot & 511) == 0)
+        printf("SEL slot %d depth %d root %llu descent %llu leaf %llu mem %llu tab %llu ucb %llu arg %llu\n", slot, depth, ts1 - ts0, ts2 - ts1,
+               ts3 - ts2, ts_mem, ts_tab, ts_ucb, ts_arg);
+#endif
+    return need_eval;
+}
+
+// One wave per game, SELECT_WAVES games per workgroup.  The leaves that need a network evaluation are
+// appended to the per-model lists with ONE global atomic per workgroup and model (positions inside
+// the workgroup come from an LDS counter): a per-wave atomicAdd on the single list counter serialises
+// 8192 same-address atomics per step and was most of this kernel's duration.
+template <int NPL>
+__global__ void __launch_bounds__(WAVE * SELECT_WAVES) k_select(Geo g, SearchCfg cfg, TreeBufs B, int n_slots)
+{
+    __shared__ int s_cnt[2], s_base[2];
+    const int slot = blockIdx.x * SELECT_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & (WAVE - 1);
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int model = -1;
+    if (slot < n_slots) model = select_one<NPL>(g, cfg, B, slot, lane);
+    int my = -1;
+    if (model >= 0 && lane == 0) my = atomicAdd(&s_cnt[model], 1);
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(B.n_eval + threadIdx.x, s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (my >= 0) (model ? B.eval_list2 : B.eval_list)[s_base[model] + my] = slot;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1101,11 +1245,16 @@ __global__ void k_get_leaves(Geo g, TreeBufs B, int n_slots, int16_t *leaf_x, ui
 __global__ void k_count_active(TreeBufs B, int n_slots, int32_t *out /*[3]: searching, ready, error*/)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_slots) return;
-    int ph = B.slots[i].phase;
-    if (ph == PH_EXPAND_ROOT || ph == PH_SIMS) atomicAdd(out + 0, 1);
-    else if (ph == PH_READY || ph == PH_EMIT) atomicAdd(out + 1, 1);
-    else if (ph == PH_ERROR) atomicAdd(out + 2, 1);
+    const int ph = i < n_slots ? B.slots[i].phase : PH_IDLE;
+    // one atomic per wave and class (same-address atomics serialise)
+    const unsigned long long m0 = __ballot(ph == PH_EXPAND_ROOT || ph == PH_SIMS);
+    const unsigned long long m1 = __ballot(ph == PH_READY || ph == PH_EMIT);
+    const unsigned long long m2 = __ballot(ph == PH_ERROR);
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        if (m0) atomicAdd(out + 0, (int)__popcll(m0));
+        if (m1) atomicAdd(out + 1, (int)__popcll(m1));
+        if (m2) atomicAdd(out + 2, (int)__popcll(m2));
+    }
 }
 
 __global__ void k_rules(Geo g, int op, int n, uint64_t *edges, int16_t *b2c2, int8_t *to_play, int8_t *just_played,
@@ -1161,7 +1310,12 @@ void tree_launch_search_begin(hipStream_t s, const Geo &g, const SearchCfg &c, c
 }
 void tree_launch_select(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
 {
-    hipLaunchKernelGGL(k_select, dim3(n_slots), dim3(WAVE), 0, s, g, c, B);
+    switch ((g.A + WAVE - 1) / WAVE) {
+    case 1: hipLaunchKernelGGL(k_select<1>, dim3((n_slots + SELECT_WAVES - 1) / SELECT_WAVES), dim3(WAVE * SELECT_WAVES), 0, s, g, c, B, n_slots); break;
+    case 2: hipLaunchKernelGGL(k_select<2>, dim3((n_slots + SELECT_WAVES - 1) / SELECT_WAVES), dim3(WAVE * SELECT_WAVES), 0, s, g, c, B, n_slots); break;
+    case 3: hipLaunchKernelGGL(k_select<3>, dim3((n_slots + SELECT_WAVES - 1) / SELECT_WAVES), dim3(WAVE * SELECT_WAVES), 0, s, g, c, B, n_slots); break;
+    default: hipLaunchKernelGGL(k_select<4>, dim3((n_slots + SELECT_WAVES - 1) / SELECT_WAVES), dim3(WAVE * SELECT_WAVES), 0, s, g, c, B, n_slots); break;
+    }
 }
 void tree_launch_expand_backup(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
 {
