@@ -190,3 +190,60 @@ def test_external_evaluator_matches_internal_formula():
         assert np.array_equal(ra[k], rb[k]), k
     a.close()
     b.close()
+
+
+def test_nan_priors_follow_numpy_argmax_order():
+    """A network that returns NaN priors: numpy's argmax picks the FIRST NaN (mcts.py:101-103 on NaN scores).
+    k_select keeps that ordering on a slow path taken only when a ballot sees a NaN; here every odd-depth
+    node has a NaN prior on its first valid move."""
+    from dotsboxesaz_amd.engine import Engine
+    assert int(np.argmax(np.array([1.0, np.nan, 3.0, np.nan]))) == 1
+    rows = cols = 3
+    d = O.dims(rows, cols)
+    A, H, W = d.A, d.H, d.W
+    sentinel = np.zeros((2, H, W), bool)
+    sentinel[1, H - 1, :] = True
+    sentinel[0, :, W - 1] = True
+    sentinel = sentinel.ravel()
+
+    def pv(f):
+        edges = np.asarray(f)[:2].ravel()
+        n = int(edges.sum())
+        p = ((np.arange(A) * 7 + n) % 5 + 1).astype(np.float32)
+        p /= p.sum()
+        if n % 2 == 1:
+            valid = np.nonzero((edges == 0) & ~sentinel)[0]
+            p[valid[0]] = np.nan
+        return p, np.float32(0.05 * ((n % 7) - 3))
+
+    def evaluate(x):
+        out = [pv(f) for f in x]
+        return np.stack([o[0] for o in out]), np.array([o[1] for o in out], np.float32)
+
+    n_slots, sims = 6, 40
+    e = Engine(rows, cols, n_slots, mcts_num_read=sims, evaluator="external")
+    starts = []
+    rng = np.random.RandomState(5)
+    for n_plies in (0, 1, 2, 3, 1, 4):
+        st, mv = O.new_state(d), []
+        for _ in range(n_plies):
+            legal = np.nonzero(O.valid_moves(d, st))[0]
+            m = int(legal[rng.randint(len(legal))])
+            O.play_(d, st, m)
+            mv.append(m)
+        starts.append(mv)
+    e.set_positions(starts)
+    e.search_external(evaluate, sims)
+    r = e.roots()
+    ev = O.Evaluator(lambda dd, s: pv(O.features(dd, s)))
+    saw_nan = False
+    for s, mv in enumerate(starts):
+        t = O.Tree(d, O.state_from_moves(d, mv))
+        vis = t.search(sims, ev)
+        pri, tv, nv, pc = t.root_arrays()
+        assert np.array_equal(r["visits"][s], vis), s
+        assert np.array_equal(r["total_value"][s].view(np.uint32), tv.view(np.uint32)), s
+        assert np.array_equal(r["priors"][s].view(np.uint64), pri.view(np.uint64)), s
+        saw_nan |= bool(np.isnan(pri).any())
+    assert saw_nan   # odd-depth roots carry the NaN prior themselves
+    e.close()
