@@ -59,6 +59,10 @@ struct NNState {
     unsigned long long *stamp_out = nullptr;    // diagnostic build (-DDBAZ_STAMP) only
     int *overflow = nullptr;                    // f16x3: set when an activation left f16's range
     float *hw = nullptr, *hb = nullptr;         // head conv1x1: [2*hc][C], [2*hc]
+    float *w0p = nullptr;                       // f16x3: conv0 as a K=32 GEMM on im2col rows, fragments [ct][hi|lo][lane][8 halves]
+    float osc0 = 1.0f;                          // f16x3: 2^-sw0
+    float *hwp = nullptr;                       // f16x3: head conv weights packed as MFMA fragments [ct][ks][hi|lo][lane][8 halves]
+    float hosc = 1.0f;                          // f16x3: 2^-(sw_h + ACT_SHIFT)
     float *hact = nullptr;                      // [batch][2][hc*HW]
     float *wfc = nullptr, *bfc = nullptr;       // head FC GEMM: packed weights [ntp+ntv][KP/16][64][4], bias [(ntp+ntv)*16]
     int KP = 0, RS4 = 0, ntp = 0, ntv = 0;
@@ -409,6 +413,10 @@ struct TowerArgs {
     const float *tb;         // [2*blocks][C]
     const float *tosc;       // f16x3 per-layer output scale
     const float *hw, *hb;    // head conv1x1 [2*hc][C], [2*hc]
+    const float *hwp;        // f16x3: packed (hi, lo) fragments of hw (nullptr: VALU head conv)
+    float hosc;
+    const float *w0p;        // f16x3: packed (hi, lo) fragments of w0 over k = tap*3 + c, padded to 32 (nullptr: VALU conv0)
+    float osc0;
     float *hact;             // out: [sample][2*hc*HW]
     int *overflow;
     int S, nblocks, hc;
@@ -440,32 +448,126 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     f32x4 *X4 = reinterpret_cast<f32x4 *>(X);
     f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
     bool ovf = false;
+    unsigned long long tE0 = 0, tE1 = 0, tL0 = 0, tL1 = 0;
+    (void)tE0; (void)tE1; (void)tL0; (void)tL1;
+    STAMP(tE0);
     // ---- conv0: stage zero-padded bn_input(planes) and the 27*C weights in the (idle) Y image
     {
         const int PW = W + 2, PH = H + 2, PP = 3 * PH * PW;
         float *pad = Y;               // [ns][3][PH][PW]
-        float *wl = Y + S * PP;       // [27][C]
+        float *wl = Y + S * PP;       // [27][C]   (VALU path only)
+        bool mfma0 = false; // the im2col image (10 units per row) must fit behind the padded planes in the idle image
+        if constexpr (PREC == 1) mfma0 = a.w0p != nullptr && ((((S * PP + 3) / 4 + 1) & ~1) + S * HW * 10 <= img_units);
+        __shared__ int slot_s[16];    // sample -> slot (S <= 13)
+        __shared__ int rowbase_s[16 * MAXT]; // position row -> offset of its 3x3 window in the padded planes
         for (int i = tid; i < ns * PP; i += NTHR) pad[i] = 0.0f;
-        for (int i = tid; i < 27 * C; i += NTHR) wl[i] = a.w0[i];
+        if (tid < ns) slot_s[tid] = a.list ? a.list[s0 + tid] : s0 + tid;
+        if (tid < R) {
+            const int sidx = tid / HW, p = tid - sidx * HW, y = p / W;
+            rowbase_s[tid] = sidx * PP + y * PW + (p - y * W);
+        }
+        if (!mfma0)
+            for (int i = tid; i < 27 * C; i += NTHR) wl[i] = a.w0[i];
         __syncthreads();
-        for (int i = tid; i < ns * 3 * HW; i += NTHR) {
-            int sidx = i / (3 * HW), r = i - sidx * 3 * HW;
-            int c = r / HW, p = r - c * HW, y = p / W, x = p - y * W;
-            const int slot = a.list ? a.list[s0 + sidx] : s0 + sidx;
-            pad[sidx * PP + (c * PH + y + 1) * PW + x + 1] = a.feat[(size_t)slot * 3 * HW + r] * a.in_s[c] + a.in_t[c];
+        {
+            // element r of a sample's planes is handled by thread r (its plane / row / column are computed once);
+            // the loads of all samples are independent
+            const int F3 = 3 * HW;
+            for (int r = tid; r < F3; r += NTHR) {
+                const int c = r / HW, p = r - c * HW, y = p / W, x = p - y * W;
+                const float sc = a.in_s[c], tc = a.in_t[c];
+                const int dst = (c * PH + y + 1) * PW + x + 1;
+                for (int sidx = 0; sidx < ns; sidx++)
+                    pad[sidx * PP + dst] = a.feat[(size_t)slot_s[sidx] * F3 + r] * sc + tc;
+            }
         }
         __syncthreads();
+        if constexpr (PREC == 1) {
+            if (mfma0) {
+                // conv0 as a GEMM on MFMA: the 27 inputs of a position (k = tap*3 + c, padded to 32) form a row of an
+                // im2col image in the tower's (hi, lo) operand format for 32 channels -- [32 halves hi | 32 halves lo |
+                // 16 B pad] = 10 units of 16 B, activation-scaled -- and the layer is one K=32 step of the f16x3 scheme
+                constexpr int MU = 10;
+                const int m_off = ((S * PP + 3) / 4 + 1) & ~1;            // units; pad image first
+                f32x4 *M4 = Y4 + m_off;
+                _Float16 *Mh = reinterpret_cast<_Float16 *>(M4);
+                for (int i = tid; i < R * 16; i += NTHR) {
+                    const int row = i >> 4, kk = (i & 15) * 2;
+                    const int rb = rowbase_s[row];
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    h2 hi, lo;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int k = kk + q;
+                        float v = 0.0f;
+                        if (k < 27) {
+                            const int tap = k / 3, c = k - tap * 3, ty = tap / 3, tx = tap - ty * 3; // constant divisors
+                            v = pad[rb + (c * PH + ty) * PW + tx] * ACT_SCALE;
+                        }
+                        ovf |= fabsf(v) > F16_GUARD;
+                        hi[q] = (_Float16)v;
+                        lo[q] = (_Float16)(v - (float)hi[q]);
+                    }
+                    *reinterpret_cast<h2 *>(Mh + (size_t)row * (MU * 8) + kk) = hi;
+                    *reinterpret_cast<h2 *>(Mh + (size_t)row * (MU * 8) + 32 + kk) = lo;
+                }
+                __syncthreads();
+                const int jr = lane & 15, gg = lane >> 4;
+                const int ct = wave & 3, half = wave >> 2;
+                const int NT = (R + 15) / 16;
+                for (int cto = ct; cto < C / 16; cto += 4) {
+                    const f32x4 *wp = reinterpret_cast<const f32x4 *>(a.w0p) + (size_t)cto * 2 * 64 + lane;
+                    u128h ah, al;
+                    ah.f = wp[0];
+                    al.f = wp[64];
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b0 + cto * 16 + gg * 4) * ACT_SCALE;
+                    _Float16 *dsth = reinterpret_cast<_Float16 *>(X4);
+                    float vmax = 0.0f;
+                    for (int t = half; t < NT; t += 2) {
+                        const int row = t * 16 + jr;
+                        const int rr = min(row, R - 1);
+                        u128h bh, bl;
+                        bh.f = M4[(size_t)rr * MU + gg];
+                        bl.f = M4[(size_t)rr * MU + 4 + gg];
+                        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bh.h, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, bh.h, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, bl.h, acc, 0, 0, 0);
+                        f32x4 v = acc * a.osc0 + bv; // activation-scaled
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                        vmax = fmaxf(vmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+                        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                        typedef float f2v __attribute__((ext_vector_type(2)));
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        union { h2v h[2]; u32x2 u; } oh, ol;
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            const f2v xx = {v[2 * q], v[2 * q + 1]};
+                            const h2v hh = __builtin_convertvector(xx, h2v);
+                            oh.h[q] = hh;
+                            ol.h[q] = __builtin_convertvector(xx - __builtin_convertvector(hh, f2v), h2v);
+                        }
+                        if (row < R) {
+                            _Float16 *ph = dsth + (size_t)row * (S4 * 8) + cto * 16 + gg * 4;
+                            *reinterpret_cast<u32x2 *>(ph) = oh.u;
+                            *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
+                        }
+                    }
+                    ovf |= vmax > F16_GUARD;
+                }
+            }
+        }
+        if (!mfma0) {
         // one work item = (row, 16 couts): its 27 inputs are read once, the weights are
         // broadcast reads (16 lanes share an address)
         for (int i = tid; i < R * (C / 16); i += NTHR) {
             const int row = i % R, cq = i / R;
-            const int sidx = row / HW, p = row - sidx * HW, y = p / W, x = p - y * W;
-            const float *pp = pad + sidx * PP;
+            const float *pp = pad + rowbase_s[row];
             float in27[27];
 #pragma unroll
             for (int tap = 0; tap < 9; tap++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) in27[tap * 3 + c] = pp[(c * PH + y + tap / 3) * PW + x + tap % 3];
+                for (int c = 0; c < 3; c++) in27[tap * 3 + c] = pp[(c * PH + tap / 3) * PW + tap % 3];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int co = cq * 16 + q * 4;
@@ -475,6 +577,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; e++) act_store<C, PREC>(X, row, co + e, fmaxf(acc[e], 0.0f), ovf);
             }
+        }
         }
         __syncthreads();
         if (tid < 3 * S4) {
@@ -522,6 +625,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         unsigned long long tb0 = 0, tb1 = 0, tk0 = 0, tk1 = 0;
         (void)tb0; (void)tb1; (void)tk0; (void)tk1;
         STAMP(tk0);
+        tL0 = tk0;
         for (int l = 0; l < NL; l++) {
             const f32x4 *src = (l & 1) ? Y4 : X4;
             f32x4 *dst = (l & 1) ? X4 : Y4;
@@ -537,14 +641,61 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         }
 #ifdef DBAZ_STAMP
         STAMP(tk1);
+        tL1 = tk1;
         if (a.stamp_out && lane == 0) {
-            unsigned long long *o = a.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 5;
+            unsigned long long *o = a.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 8;
             o[0] = stamps[0]; o[1] = stamps[1]; o[2] = stamps[2]; o[3] = stamps[3]; o[4] = tk1 - tk0;
         }
 #endif
     }
     // ---- head conv1x1 (both heads), results staged in Y as [sample][oc][pos] and written out coalesced
-    {
+    bool heads_done = false;
+    if constexpr (PREC == 1) {
+        if (a.hwp) {
+            // f16x3 on MFMA, the tower's operand format with a single (centre) tap: wave = (16-output tile,
+            // group of position tiles); A = packed weight fragments from L2, B = this tile's own rows
+            constexpr int KS = C / 32, LO = C / 8;
+            const int OC = 2 * a.hc, n_ct = ((OC + 15) & ~15) / 16, ngrp = 8 / n_ct;
+            const int ct = wave % n_ct, grp = wave / n_ct;
+            const int NT = (R + 15) / 16;
+            float *stage = Y; // [ns][OC][HW]
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(a.hwp) + (size_t)ct * KS * 2 * 64 + lane;
+            u128h ah[KS], al[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) { ah[ks].f = wp[(size_t)ks * 128]; al[ks].f = wp[(size_t)ks * 128 + 64]; }
+            const int oc0 = ct * 16 + gq * 4;
+            f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (oc0 + r < OC) bv[r] = a.hb[oc0 + r];
+            for (int t = grp; t < NT; t += ngrp) {
+                const int row = t * 16 + jrow;
+                const int rr = min(row, R - 1);
+                const f32x4 *bp = X4 + (size_t)rr * S4 + gq;
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    u128h bh, bl;
+                    bh.f = bp[ks * 4];
+                    bl.f = bp[ks * 4 + LO];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks].h, bh.h, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks].h, bh.h, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks].h, bl.h, acc, 0, 0, 0);
+                }
+                if (row < R) {
+                    const int sidx = row / HW, pp = row - sidx * HW;
+                    const f32x4 v = acc * a.hosc + bv;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (oc0 + r < OC) stage[(sidx * OC + oc0 + r) * HW + pp] = fmaxf(v[r], 0.0f);
+                }
+            }
+            __syncthreads();
+            float *o = a.hact + (size_t)s0 * OC * HW;
+            for (int i = tid; i < ns * OC * HW; i += NTHR) o[i] = stage[i];
+            heads_done = true;
+        }
+    }
+    if (!heads_done) {
         const int OC = 2 * a.hc;
         float *wl = Y;                         // [OC][C+4]
         float *stage = Y + OC * (C + 4);       // [ns][OC][HW]
@@ -577,6 +728,15 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         for (int i = tid; i < ns * OC * HW; i += NTHR) o[i] = stage[i];
     }
     if (PREC == 1 && ovf) atomicOr(a.overflow, 1);
+#ifdef DBAZ_STAMP
+    STAMP(tE1);
+    if (PREC == 1 && a.stamp_out && lane == 0) {
+        unsigned long long *o = a.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[5] = tL0 - tE0; // conv0 phase (staging, VALU conv, zero regions)
+        o[6] = tE1 - tL1; // head conv1x1 phase + output
+        o[7] = tE1 - tE0; // whole workgroup
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -618,6 +778,9 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_simple_trunk(Geo g, SimpleA
     f32x4 *X4 = reinterpret_cast<f32x4 *>(X);
     f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
     bool ovf = false;
+    unsigned long long tE0 = 0, tE1 = 0, tL0 = 0, tL1 = 0;
+    (void)tE0; (void)tE1; (void)tL0; (void)tL1;
+    STAMP(tE0);
     {
         const int PW = W + 2, PH = H + 2, PP = 3 * PH * PW;
         float *pad = Y;
@@ -1252,6 +1415,32 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         }
         nn->w0 = nn_upload(nn, pk);
         nn->b0 = nn_upload(nn, bias);
+        nn->w0p = nullptr;
+        if (nn->precision == 1 && C >= 32) {
+            double mx = 0;
+            for (float v : pk) mx = std::max(mx, fabs((double)v));
+            int sw = 0;
+            if (mx > 0) { int e; frexp(mx, &e); sw = 14 - e; }
+            sw = std::max(-24, std::min(24, sw));
+            const double wscale = ldexp(1.0, sw);
+            const int n_ct = C / 16;
+            std::vector<_Float16> hp((size_t)n_ct * 2 * 64 * 8, (_Float16)0.0f);
+            for (int ct = 0; ct < n_ct; ct++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 8; e++) {
+                        const int co = ct * 16 + (lane & 15), k = 8 * (lane >> 4) + e;
+                        if (k >= 27) continue;
+                        const float v = (float)((double)pk[(size_t)k * C + co] * wscale);
+                        const _Float16 h = (_Float16)v;
+                        const size_t base = (size_t)ct * 2 * 64 * 8;
+                        hp[base + (size_t)lane * 8 + e] = h;
+                        hp[base + 64 * 8 + (size_t)lane * 8 + e] = (_Float16)(v - (float)h);
+                    }
+            std::vector<float> asf(hp.size() / 2);
+            memcpy(asf.data(), hp.data(), hp.size() * 2);
+            nn->w0p = nn_upload(nn, asf);
+            nn->osc0 = (float)ldexp(1.0, -sw);
+        }
     }
     {
         std::vector<float> pk_all, bias_all;
@@ -1269,8 +1458,8 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         if (!nn->tw || !nn->tb || !nn->tosc || !nn->overflow) { err = "hipMalloc failed (tower weights)"; return DBAZ_EDEVICE; }
         (void)hipMemset(nn->overflow, 0, 16);
 #ifdef DBAZ_STAMP
-        nn->stamp_out = nn_alloc<unsigned long long>(nn, (size_t)nn->max_batch * 8 * 5);
-        (void)hipMemset(nn->stamp_out, 0, (size_t)nn->max_batch * 8 * 5 * 8);
+        nn->stamp_out = nn_alloc<unsigned long long>(nn, (size_t)nn->max_batch * 8 * 8);
+        (void)hipMemset(nn->stamp_out, 0, (size_t)nn->max_batch * 8 * 8 * 8);
 #endif
     }
     // heads: conv1x1 + BN folded, rows [policy hc | value hc]
@@ -1290,6 +1479,35 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         }
         nn->hw = nn_upload(nn, hw);
         nn->hb = nn_upload(nn, hb);
+        nn->hwp = nullptr;
+        const int OCP = (2 * hc + 15) & ~15, n_ct = OCP / 16;
+        if (nn->precision == 1 && C >= 32 && (n_ct == 1 || n_ct == 2 || n_ct == 4 || n_ct == 8)) {
+            // same operand format as the tower layers (pack_conv): weights * 2^sw_h split into halves
+            double mx = 0;
+            for (float v : hw) mx = std::max(mx, fabs((double)v));
+            int sw = 0;
+            if (mx > 0) { int e; frexp(mx, &e); sw = 14 - e; }
+            sw = std::max(-24, std::min(24, sw));
+            const double wscale = ldexp(1.0, sw);
+            const int KS = C / 32;
+            std::vector<_Float16> hp((size_t)n_ct * KS * 2 * 64 * 8, (_Float16)0.0f);
+            for (int ct = 0; ct < n_ct; ct++)
+                for (int ks = 0; ks < KS; ks++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int e = 0; e < 8; e++) {
+                            const int oc = ct * 16 + (lane & 15), ci = ks * 32 + 8 * (lane >> 4) + e;
+                            if (oc >= 2 * hc) continue;
+                            const float v = (float)((double)hw[(size_t)oc * C + ci] * wscale);
+                            const _Float16 h = (_Float16)v;
+                            const size_t base = (((size_t)ct * KS + ks) * 2) * 64 * 8;
+                            hp[base + (size_t)lane * 8 + e] = h;
+                            hp[base + 64 * 8 + (size_t)lane * 8 + e] = (_Float16)(v - (float)h);
+                        }
+            std::vector<float> asf(hp.size() / 2);
+            memcpy(asf.data(), hp.data(), hp.size() * 2);
+            nn->hwp = nn_upload(nn, asf);
+            nn->hosc = (float)ldexp(1.0, -(sw + ACT_SHIFT));
+        }
         auto wp = sd_get(nn, "policy_head.fc.weight", (size_t)A * K, err); if (!wp) return DBAZ_EINVAL;
         auto bp = sd_get(nn, "policy_head.fc.bias", A, err); if (!bp) return DBAZ_EINVAL;
         auto w0 = sd_get(nn, "value_head.fc0.weight", (size_t)vf * K, err); if (!w0) return DBAZ_EINVAL;
@@ -1390,7 +1608,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     }
     TowerArgs ta;
     ta.feat = feat; ta.list = list_dev; ta.n_dev = n_dev; ta.in_s = nn->in_s; ta.in_t = nn->in_t; ta.w0 = nn->w0; ta.b0 = nn->b0;
-    ta.tw = nn->tw; ta.tb = nn->tb; ta.tosc = nn->tosc; ta.hw = nn->hw; ta.hb = nn->hb; ta.hact = nn->hact;
+    ta.tw = nn->tw; ta.tb = nn->tb; ta.tosc = nn->tosc; ta.hw = nn->hw; ta.hb = nn->hb; ta.hwp = nn->hwp; ta.hosc = nn->hosc; ta.w0p = nn->w0p; ta.osc0 = nn->osc0; ta.hact = nn->hact;
     ta.overflow = nn->overflow; ta.S = nn->S; ta.nblocks = nn->blocks; ta.hc = hc;
     ta.stamp_out = nn->stamp_out;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
@@ -1421,7 +1639,7 @@ const char *nn_tower_kernel_name(const NNState *nn) { (void)nn; return "k_tower"
 int nn_read_stamps(NNState *nn, unsigned long long *out, int n_wg)
 {
     if (!nn || !nn->stamp_out) return -1;
-    return (int)hipMemcpy(out, nn->stamp_out, (size_t)n_wg * 8 * 5 * 8, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out, nn->stamp_out, (size_t)n_wg * 8 * 8 * 8, hipMemcpyDeviceToHost);
 }
 
 int nn_overflowed(NNState *nn)

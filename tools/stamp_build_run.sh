@@ -5,12 +5,12 @@ set -e
 cd "$(dirname "$0")/.."
 D=gpurun_out/stamp_build
 mkdir -p $D
-for f in tree engine nn; do
-  extra=""; [ $f = tree ] && extra="-ffp-contract=off"
+for f in tree engine nn replay; do
+  extra=""; [ $f = tree ] && extra="-ffp-contract=off"; [ $f = replay ] && extra="-ffp-contract=off"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DDBAZ_STAMP $extra -c dotsboxesaz_amd/csrc/$f.hip -o $D/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libdbaz_hip.so $D/tree.o $D/engine.o $D/nn.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libdbaz_hip.so $D/tree.o $D/engine.o $D/nn.o $D/replay.o
 python - <<'PY'
 import ctypes as C, numpy as np, torch, sys
 sys.path.insert(0, ".")
@@ -26,7 +26,7 @@ X = np.random.RandomState(0).randint(0, 2, size=(8192, 3, 7, 7)).astype(np.float
 for _ in range(3):
     e.predict(X)
 n_wg = 2048
-out = np.zeros((n_wg, 8, 5), np.uint64)
+out = np.zeros((n_wg, 8, 8), np.uint64)
 L = _lib.load()
 L.dbaz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 rc = L.dbaz_debug_read_stamps(e.h, out.ctypes.data, n_wg)
@@ -39,4 +39,8 @@ for i, nme in enumerate(names):
 print("per layer: total %.0f, main %.0f (MFMA floor 7 tiles: %d, 6 tiles: %d)" % (tot.mean() / 40, o[..., 1].mean() / 40, 18 * 21 * 16, 18 * 18 * 16))
 for w in range(8):
     print("wave", w, ["%.0f" % (o[:, w, i].mean() / 40) for i in range(5)])
+whole = o[..., 7].mean()
+print("whole workgroup %.0f cycles: conv0 phase %.0f (%.1f %%), 40 layers %.0f (%.1f %%), head convs + output %.0f (%.1f %%)"
+      % (whole, o[..., 5].mean(), 100 * o[..., 5].mean() / whole, tot.mean(), 100 * tot.mean() / whole, o[..., 6].mean(),
+         100 * o[..., 6].mean() / whole))
 PY
