@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
                 }
                 __syncthreads();
                 const int jr = lane & 15, gg = lane >> 4;
-                const int ct = wave & 3, half = wave >> 2;
+                const int ct = wave & 3, half = wave >> 2, nhalf = NTHR >> 8;
                 const int NT = (R + 15) / 16;
                 for (int cto = ct; cto < C / 16; cto += 4) {
                     const f32x4 *wp = reinterpret_cast<const f32x4 *>(a.w0p) + (size_t)cto * 2 * 64 + lane;
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
                     const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b0 + cto * 16 + gg * 4) * ACT_SCALE;
                     _Float16 *dsth = reinterpret_cast<_Float16 *>(X4);
                     float vmax = 0.0f;
-                    for (int t = half; t < NT; t += 2) {
+                    for (int t = half; t < NT; t += nhalf) {
                         const int row = t * 16 + jr;
                         const int rr = min(row, R - 1);
                         u128h bh, bl;
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
             const f32x4 *src = (l & 1) ? Y4 : X4;
             f32x4 *dst = (l & 1) ? X4 : Y4;
             if (first) conv_lds_f32<C, NTA>(src, dst, a.tw + (size_t)l * wl, a.tb + l * C, vm, rowbase, zbase, W, R, wave, lane, l & 1, tbase);
-            else conv_lds_f32<C, NTB>(src, dst, a.tw + (size_t)l * wl, a.tb + l * C, vm, rowbase, zbase, W, R, wave, lane, l & 1, tbase);
+            else if constexpr (NTB > 0) conv_lds_f32<C, NTB>(src, dst, a.tw + (size_t)l * wl, a.tb + l * C, vm, rowbase, zbase, W, R, wave, lane, l & 1, tbase);
             __syncthreads();
         }
     } else {
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
             f32x4 *dst = (l & 1) ? X4 : Y4;
             const f32x4 *nxt = l + 1 < NL ? tw4 + (size_t)(l + 1) * wl : nullptr;
             if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase, nullptr, nullptr, pre, nxt, stamps);
-            else conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase, nullptr, nullptr, pre, nxt, stamps);
+            else if constexpr (NTB > 0) conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase, nullptr, nullptr, pre, nxt, stamps);
             STAMP(tb0);
             __syncthreads();
             STAMP(tb1);
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
             // f16x3 on MFMA, the tower's operand format with a single (centre) tap: wave = (16-output tile,
             // group of position tiles); A = packed weight fragments from L2, B = this tile's own rows
             constexpr int KS = C / 32, LO = C / 8;
-            const int OC = 2 * a.hc, n_ct = ((OC + 15) & ~15) / 16, ngrp = 8 / n_ct;
+            const int OC = 2 * a.hc, n_ct = ((OC + 15) & ~15) / 16, ngrp = (NTHR >> 6) / n_ct;
             const int ct = wave % n_ct, grp = wave / n_ct;
             const int NT = (R + 15) / 16;
             float *stage = Y; // [ns][OC][HW]
