@@ -75,6 +75,7 @@ struct NNState {
     float *sn_w1 = nullptr, *sn_b1 = nullptr, *sn_ps1 = nullptr, *sn_pt1 = nullptr; // fc1
     size_t sn_lds = 0;
     int S = 1, NT = 1, NTT = 7;                 // samples / position tiles per conv workgroup (NTT: compiled tile count)
+    int S_small = 0, S_mid = 0, cus = 256;      // tail launches: samples per workgroup of the <2,2> / <4,4> variants (0: unused)
     size_t conv_lds = 0;
 };
 
@@ -420,6 +421,8 @@ struct TowerArgs {
     float *hact;             // out: [sample][2*hc*HW]
     int *overflow;
     int S, nblocks, hc;
+    // tail handling (see nn_forward): role 0 = main launch, 1 / 2 = tail launches with fewer samples per workgroup
+    int role, S_main, S_small, S_mid, cus;
     unsigned long long *stamp_out; // diagnostic build only
 };
 
@@ -431,10 +434,29 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     constexpr int S4 = STRIDE / 4;
     const int n = *a.n_dev;
     const int S = a.S;
-    const int s0 = blockIdx.x * S;
-    if (s0 >= n) return;
+    // Every workgroup of a launch takes the same time, so the launch costs ceil(workgroups / CUs) rounds and a
+    // nearly empty last round costs a full one.  The samples beyond the last FULL round of the main launch are
+    // therefore left to a tail launch with fewer samples (and position tiles) per workgroup whenever one round of
+    // those smaller, faster workgroups can take them; every launch derives the split from n on the device.
+    int first_sample = 0, limit = n;
+    {
+        const int per_round = a.cus * a.S_main;
+        const int n_full = per_round > 0 ? (n / per_round) * per_round : 0;
+        const int tail = n - n_full;
+        int mode = 0;
+        if (tail > 0 && a.S_small > 0 && tail <= a.cus * a.S_small) mode = 1;
+        else if (tail > 0 && a.S_mid > 0 && tail <= a.cus * a.S_mid) mode = 2;
+        if (a.role == 0) {
+            if (mode) limit = n_full;
+        } else {
+            if (mode != a.role) return;
+            first_sample = n_full;
+        }
+    }
+    const int s0 = first_sample + blockIdx.x * S;
+    if (s0 >= limit) return;
     const int HW = g.HW, W = g.W, H = g.H;
-    const int ns = min(S, n - s0);
+    const int ns = min(S, limit - s0);
     const int R = ns * HW;           // valid rows in this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NTHR = blockDim.x;
     // Zero REGION (3 rows, starting at a multiple of 16 float4 units) behind the S*HW rows of each
@@ -1215,9 +1237,8 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
 
 // launches (or, with attr_only, raises the dynamic-LDS limit of) the instantiation for (C, NTT, PREC)
 template <int C, int NTA, int NTB>
-static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
+static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, int grid, bool attr_only)
 {
-    const int grid = (max_n + nn->S - 1) / nn->S;
     if constexpr (C >= 32) {
         if (nn->precision == 1) {
             if (attr_only)
@@ -1232,21 +1253,22 @@ static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, in
     return hipSuccess;
 }
 template <int C>
-static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
+static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, int ntt, int grid, bool attr_only)
 {
-    switch (nn->NTT) {
-    case 2: return tower_inst<C, 2, 2>(nn, s, ta, max_n, attr_only);
-    case 4: return tower_inst<C, 4, 4>(nn, s, ta, max_n, attr_only);
-    default: return tower_inst<C, 7, 6>(nn, s, ta, max_n, attr_only);
+    switch (ntt) {
+    case 2: return tower_inst<C, 2, 2>(nn, s, ta, grid, attr_only);
+    case 4: return tower_inst<C, 4, 4>(nn, s, ta, grid, attr_only);
+    default: return tower_inst<C, 7, 6>(nn, s, ta, grid, attr_only);
     }
 }
-static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const TowerArgs &ta, int max_n, bool attr_only)
+// ntt: tiles per wave of the instantiation (7 -> <7,6>, 4 -> <4,4>, 2 -> <2,2>)
+static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const TowerArgs &ta, int ntt, int grid, bool attr_only)
 {
     switch (nn->C) {
-    case 16: return tower_inst_c<16>(nn, s, ta, max_n, attr_only);
-    case 32: return tower_inst_c<32>(nn, s, ta, max_n, attr_only);
-    case 64: return tower_inst_c<64>(nn, s, ta, max_n, attr_only);
-    default: return tower_inst_c<128>(nn, s, ta, max_n, attr_only);
+    case 16: return tower_inst_c<16>(nn, s, ta, ntt, grid, attr_only);
+    case 32: return tower_inst_c<32>(nn, s, ta, ntt, grid, attr_only);
+    case 64: return tower_inst_c<64>(nn, s, ta, ntt, grid, attr_only);
+    default: return tower_inst_c<128>(nn, s, ta, ntt, grid, attr_only);
     }
 }
 
@@ -1569,7 +1591,24 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     nn->NT = (S * HW + 15) / 16;
     nn->conv_lds = lds_bytes(S);
     nn->NTT = nn->NT > 8 ? 7 : (nn->NT > 4 ? 4 : 2); // tiles per wave; two waves cover 2*NTT >= NT tiles
-    hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), 0, true);
+    // tail variants: <2,2> holds 64 rows, <4,4> 128 rows
+    nn->S_small = nn->S_mid = 0;
+    if (nn->NTT == 7) {
+        nn->S_mid = std::min(128 / HW, nn->S - 1);
+        nn->S_small = std::min(64 / HW, nn->S_mid - 1);
+    } else if (nn->NTT == 4) {
+        nn->S_small = std::min(64 / HW, nn->S - 1);
+    }
+    if (nn->S_mid < 0) nn->S_mid = 0;
+    if (nn->S_small < 0) nn->S_small = 0;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            nn->cus = cus;
+    }
+    hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true);
+    if (he == hipSuccess && nn->S_mid > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 4, 0, true);
+    if (he == hipSuccess && nn->S_small > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 2, 0, true);
     if (he != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); return DBAZ_EDEVICE; }
     nn->ready = true;
     return DBAZ_OK;
@@ -1612,7 +1651,17 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     ta.overflow = nn->overflow; ta.S = nn->S; ta.nblocks = nn->blocks; ta.hc = hc;
     ta.stamp_out = nn->stamp_out;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    (void)tower_dispatch(nn, s, ta, max_n, false);
+    ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.cus = nn->cus;
+    ta.role = 0; ta.S = nn->S;
+    (void)tower_dispatch(nn, s, ta, nn->NTT, (max_n + nn->S - 1) / nn->S, false);
+    if (nn->S_small > 0) { // tail <= cus * S_small samples: one round of <2,2> workgroups
+        ta.role = 1; ta.S = nn->S_small;
+        (void)tower_dispatch(nn, s, ta, 2, nn->cus, false);
+    }
+    if (nn->S_mid > 0) {   // tail <= cus * S_mid samples: one round of <4,4> workgroups
+        ta.role = 2; ta.S = nn->S_mid;
+        (void)tower_dispatch(nn, s, ta, 4, nn->cus, false);
+    }
     if (ev_end) (void)hipEventRecord(ev_end, s);
     HeadArgs ha;
     ha.list = list_dev; ha.n_dev = n_dev; ha.hact = nn->hact; ha.wfc = nn->wfc; ha.bfc = nn->bfc; ha.wv1 = nn->wv1; ha.bv1 = nn->bv1;
