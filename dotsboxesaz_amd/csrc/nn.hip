@@ -470,9 +470,12 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     f32x4 *X4 = reinterpret_cast<f32x4 *>(X);
     f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
     bool ovf = false;
-    unsigned long long tE0 = 0, tE1 = 0, tL0 = 0, tL1 = 0;
-    (void)tE0; (void)tE1; (void)tL0; (void)tL1;
+    unsigned long long tE0 = 0, tE1 = 0, tL0 = 0, tL1 = 0, tR0 = 0;
+    (void)tE0; (void)tE1; (void)tL0; (void)tL1; (void)tR0;
     STAMP(tE0);
+#ifdef DBAZ_STAMP
+    tR0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- conv0: stage zero-padded bn_input(planes) and the 27*C weights in the (idle) Y image
     {
         const int PW = W + 2, PH = H + 2, PP = 3 * PH * PW;
@@ -665,7 +668,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         STAMP(tk1);
         tL1 = tk1;
         if (a.stamp_out && lane == 0) {
-            unsigned long long *o = a.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 8;
+            unsigned long long *o = a.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 10;
             o[0] = stamps[0]; o[1] = stamps[1]; o[2] = stamps[2]; o[3] = stamps[3]; o[4] = tk1 - tk0;
         }
 #endif
@@ -753,10 +756,11 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 #ifdef DBAZ_STAMP
     STAMP(tE1);
     if (PREC == 1 && a.stamp_out && lane == 0) {
-        unsigned long long *o = a.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 8;
+        unsigned long long *o = a.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 10;
         o[5] = tL0 - tE0; // conv0 phase (staging, VALU conv, zero regions)
         o[6] = tE1 - tL1; // head conv1x1 phase + output
         o[7] = tE1 - tE0; // whole workgroup
+        o[8] = __builtin_amdgcn_s_memrealtime() - tR0; // the same interval in 100 MHz ticks: clock = o[7] / o[8] * 100 MHz
     }
 #endif
 }
@@ -800,9 +804,12 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_simple_trunk(Geo g, SimpleA
     f32x4 *X4 = reinterpret_cast<f32x4 *>(X);
     f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
     bool ovf = false;
-    unsigned long long tE0 = 0, tE1 = 0, tL0 = 0, tL1 = 0;
-    (void)tE0; (void)tE1; (void)tL0; (void)tL1;
+    unsigned long long tE0 = 0, tE1 = 0, tL0 = 0, tL1 = 0, tR0 = 0;
+    (void)tE0; (void)tE1; (void)tL0; (void)tL1; (void)tR0;
     STAMP(tE0);
+#ifdef DBAZ_STAMP
+    tR0 = __builtin_amdgcn_s_memrealtime();
+#endif
     {
         const int PW = W + 2, PH = H + 2, PP = 3 * PH * PW;
         float *pad = Y;
@@ -1494,8 +1501,8 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         if (!nn->tw || !nn->tb || !nn->tosc || !nn->overflow) { err = "hipMalloc failed (tower weights)"; return DBAZ_EDEVICE; }
         (void)hipMemset(nn->overflow, 0, 16);
 #ifdef DBAZ_STAMP
-        nn->stamp_out = nn_alloc<unsigned long long>(nn, (size_t)nn->max_batch * 8 * 8);
-        (void)hipMemset(nn->stamp_out, 0, (size_t)nn->max_batch * 8 * 8 * 8);
+        nn->stamp_out = nn_alloc<unsigned long long>(nn, (size_t)nn->max_batch * 8 * 10);
+        (void)hipMemset(nn->stamp_out, 0, (size_t)nn->max_batch * 8 * 10 * 8);
 #endif
     }
     // heads: conv1x1 + BN folded, rows [policy hc | value hc]
@@ -1702,7 +1709,7 @@ const char *nn_tower_kernel_name(const NNState *nn) { (void)nn; return "k_tower"
 int nn_read_stamps(NNState *nn, unsigned long long *out, int n_wg)
 {
     if (!nn || !nn->stamp_out) return -1;
-    return (int)hipMemcpy(out, nn->stamp_out, (size_t)n_wg * 8 * 8 * 8, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out, nn->stamp_out, (size_t)n_wg * 8 * 10 * 8, hipMemcpyDeviceToHost);
 }
 
 int nn_overflowed(NNState *nn)
