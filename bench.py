@@ -112,7 +112,7 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
     c1 = eng.counters()
     if c1["error_slots"]:
         raise SystemExit("engine reported %d slots in error (node pool exhausted?)" % c1["error_slots"])
-    m = {k: c1[k] - c0[k] for k in ("expansions", "nn_evals", "sum_path", "terminal_leaves", "moves_played")}
+    m = {k: c1[k] - c0[k] for k in ("expansions", "nn_evals", "sum_path", "terminal_leaves", "moves_played", "cache_hits")}
     m.update(dt=dt, ms_total=c1["ms_total"], ms_nn_tower=c1["ms_nn_tower"], pool_high_water=c1["pool_high_water"],
              nodes_per_slot=eng.cfg.nodes_per_slot or 10 * (args.sims + 2), E=eng.E)
     if dist is not None:
@@ -152,6 +152,7 @@ def full_games(args, rank, local_rank, world, torch):
            "rows": int(len(got["z"])), "rows_per_game": len(got["z"]) / max(1, c["games_finished"]),
            "mean_path_len": c["sum_path"] / max(1, c["expansions"]),
            "terminal_leaf_fraction": c["terminal_leaves"] / max(1, c["expansions"]),
+           "cache_hit_fraction": c["cache_hits"] / max(1, c["expansions"]),
            "pool_high_water": c["pool_high_water"], "steps": c["steps"],
            "config": {"workload": "%dx%d board, %d complete games on %d slots, %d sims/move, evaluator=%s %dx%d, precision %d"
                                   % (rows, cols, args.full_games, args.slots, args.sims, args.evaluator, args.blocks,
@@ -320,6 +321,7 @@ def main():
             "per_gpu": m["exp_all"] / m["dt_max"] / world,
             "nn_evals_per_sec": m["evals_all"] / m["dt_max"],
             "mean_path_len": spath / max(1, exp), "terminal_leaf_fraction": term / max(1, exp),
+            "cache_hit_fraction": m["cache_hits"] / max(1, exp),
             "pool_high_water": m["pool_high_water"], "nodes_per_slot": m["nodes_per_slot"],
             "moves_played": m["moves_played"],
         }

@@ -36,6 +36,7 @@ class Config(C.Structure):
         ("n_temp", C.c_int32), ("temp_idx", C.c_int32 * 8), ("temp_val", C.c_double * 8),
         ("evaluator", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64), ("max_out_rows", C.c_int32),
         ("nn_precision", C.c_int32), ("match_play", C.c_int32), ("evaluator2", C.c_int32),
+        ("transposition_cache", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -45,7 +46,7 @@ class Counters(C.Structure):
         ("sum_path", C.c_int64), ("games_finished", C.c_int64), ("rows_ready", C.c_int64), ("moves_played", C.c_int64),
         ("pool_high_water", C.c_int64), ("active_slots", C.c_int32), ("error_slots", C.c_int32), ("blocked_slots", C.c_int32), ("reserved", C.c_int32),
         ("ms_total", C.c_double), ("ms_tree", C.c_double), ("ms_nn", C.c_double), ("nn_launches", C.c_int64),
-        ("ms_nn_tower", C.c_double),
+        ("ms_nn_tower", C.c_double), ("cache_hits", C.c_int64),
     ]
 
 

@@ -62,6 +62,9 @@ struct Slot {
     int64_t n_search, sum_path, n_eval, n_term;
     int32_t ff_plies;        // pending fast-forward plies (benchmark population)
     int32_t model;           // match play: which of the two evaluators serves this slot's current search
+    int32_t leaf_hit;        // transposition cache: expanded node of this tree with the leaf's position, or -1
+    int32_t tt_epoch;        // 1..255, bumped at every re-root / new game (stale table entries are preferred victims)
+    int64_t n_hit;
 };
 
 struct PathEnt {
@@ -108,6 +111,8 @@ struct TreeBufs {
     int32_t *eval_list2;// [n_slots] same for model 1 (match play)
     int32_t *n_eval;   // [2] list lengths
     int32_t *remap;    // [n_slots][cap] compaction scratch
+    unsigned long long *tt; // [n_slots][tt_mask+1] transposition table (tag24 | epoch8 | node index), nullptr = off
+    int32_t tt_mask;
     const double *pbc_table;  // log((N+base+1)/base)+cpuct for N < table_n (host libm)
     const double *sqrt_table; // sqrt(N)
     // self-play rows of the game in flight

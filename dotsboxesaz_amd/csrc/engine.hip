@@ -232,6 +232,17 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     CREATE_CHECK(dmalloc(e, &B.eval_list2, ns));
     CREATE_CHECK(dmalloc(e, &B.n_eval, 4));
     CREATE_CHECK(dmalloc(e, &B.remap, ns * g.cap, false));
+    B.tt = nullptr;
+    B.tt_mask = 0;
+    {
+        auto nn_ev = [](int ev) { return ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN; };
+        if (cfg->transposition_cache == 0 && (nn_ev(cfg->evaluator) || (cfg->match_play && nn_ev(cfg->evaluator2)))) {
+            size_t tcap = 64;
+            while (tcap < 2 * (size_t)g.cap) tcap <<= 1; // <= 50 % load even when every node of the pool is a distinct position
+            CREATE_CHECK(dmalloc(e, &B.tt, ns * tcap));
+            B.tt_mask = (int32_t)(tcap - 1);
+        }
+    }
     CREATE_CHECK(dmalloc(e, &B.row_x, ns * rcap * F, false));
     CREATE_CHECK(dmalloc(e, &B.row_vis, ns * rcap * g.A, false));
     CREATE_CHECK(dmalloc(e, &B.row_meta, ns * rcap, false));
@@ -835,12 +846,13 @@ static int slot_summary(dbaz_engine *e, dbaz_counters *c)
 {
     std::vector<Slot> hs(e->n_slots);
     HIP_CHECK_RET(e, hipMemcpy(hs.data(), e->B.slots, sizeof(Slot) * e->n_slots, hipMemcpyDeviceToHost));
-    c->expansions = c->nn_evals = c->terminal_leaves = c->sum_path = 0;
+    c->expansions = c->nn_evals = c->terminal_leaves = c->sum_path = c->cache_hits = 0;
     c->active_slots = c->error_slots = c->blocked_slots = 0;
     c->pool_high_water = 0;
     for (const Slot &s : hs) {
         c->expansions += s.n_search;
         c->nn_evals += s.n_eval;
+        c->cache_hits += s.n_hit;
         c->terminal_leaves += s.n_term;
         c->sum_path += s.sum_path;
         if (s.phase == PH_ERROR) c->error_slots++;

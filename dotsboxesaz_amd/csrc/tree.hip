@@ -180,6 +180,19 @@ __device__ __forceinline__ float formula_v(uint64_t h, int kind)
     return ((float)u - 32768.0f) / 32768.0f;
 }
 
+// ---- per-game transposition table (the reference's (p, v) cache by position hash, utils/proxies.py:35-43) ----
+// Entry = tag24 | epoch8 | node index.  A hit is only taken after the candidate node of the LIVE tree has been
+// checked: same network input (edges and the mover's boxes_to_close, exactly the reference's hash) and already
+// expanded -- so stale entries (old epochs, renumbered nodes) can never return a wrong result, and (p, v) need not
+// be stored: the twin's prior row IS masked(p) normalised for the same valid moves, its value sits in meta dword 12.
+#define TT_PROBES 4
+__device__ __forceinline__ int tt_mover_b2c(const GState &st) { return st.to_play == 0 ? st.b2c0 : st.b2c1; }
+__device__ __forceinline__ unsigned tt_epoch_byte(int epoch) { return (unsigned)(epoch % 255) + 1u; }
+__device__ __forceinline__ unsigned long long tt_entry(uint64_t h, unsigned ep, int idx)
+{
+    return ((h >> 40) << 40) | ((unsigned long long)ep << 32) | (unsigned long long)(unsigned)idx;
+}
+
 // ------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (production move sampling / Dirichlet noise; the reference
 // uses numpy's global MT19937, which parity tests replace by injected draws)
@@ -613,6 +626,29 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
             f[i] = (float)gs_feature(g, m.st, i);
         const int ev = model ? cfg.evaluator2 : cfg.evaluator;
         if (ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN) need_eval = model;
+        int hit = -1;
+        if (need_eval >= 0 && B.tt) {
+            // lanes 0..TT_PROBES-1 read the probe window; a candidate is verified against the live tree
+            const uint64_t h = formula_hash(m.st);
+            const unsigned long long *tt = B.tt + (size_t)slot * ((size_t)B.tt_mask + 1);
+            unsigned long long ent = 0;
+            if (lane < TT_PROBES) ent = tt[((unsigned)h + (unsigned)lane) & (unsigned)B.tt_mask];
+            unsigned long long cand = __ballot(lane < TT_PROBES && ent != 0ull && (ent >> 40) == (h >> 40));
+            const int mb = tt_mover_b2c(m.st);
+            while (cand && hit < 0) {
+                const int pl = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const int idx = (int)(unsigned)__shfl(ent, pl);
+                if (idx >= 0 && idx < n_nodes && idx != cur) {
+                    const NodeMeta tm = load_meta(pool, g, idx);
+                    if ((tm.flags & NF_EXPANDED) && !(tm.flags & NF_TERMINAL) && tm.st.e0 == m.st.e0 && tm.st.e1 == m.st.e1 &&
+                        tm.st.e2 == m.st.e2 && tm.st.e3 == m.st.e3 && tt_mover_b2c(tm.st) == mb)
+                        hit = idx;
+                }
+            }
+            if (hit >= 0) need_eval = -1;
+        }
+        if (lane == 0) S->leaf_hit = hit;
     }
 #ifdef DBAZ_STAMP
     TSTAMP(ts3);
@@ -663,23 +699,48 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
     NodeMeta lm = load_meta(pool, g, leaf);
     uint32_t *nd = node_ptr(pool, g, leaf);
     float v;
+    int hit = -1;
     if (!(lm.flags & NF_TERMINAL)) {
         float *Prow = reinterpret_cast<float *>(nd + META_DW);
-        uint64_t h = 0;
         const int ev = (cfg.match_play && S->model) ? cfg.evaluator2 : cfg.evaluator;
         const bool formula = ev == DBAZ_EVAL_FORMULA_HASH || ev == DBAZ_EVAL_FORMULA_UNIFORM;
-        if (formula) h = formula_hash(lm.st);
-        const float *ep = B.evalP + (size_t)slot * g.AS;
-        for (int i = lane; i < A; i += WAVE) {
-            float p = formula ? formula_p(h, i, ev) : ep[i];
-            ldsf[i] = p * (gs_valid(g, lm.st, i) ? 1.0f : 0.0f); // child_priors * valid
+        if (B.tt && !formula) hit = S->leaf_hit;
+        if (hit >= 0) {
+            // transposition: the twin's row is masked(p) / sum for the same valid moves, its v the same network output
+            const uint32_t *tw = node_ptr(pool, g, hit);
+            const float *Psrc = reinterpret_cast<const float *>(tw + META_DW);
+            for (int i = lane; i < A; i += WAVE) Prow[i] = Psrc[i];
+            v = __uint_as_float(tw[12]);
+        } else {
+            uint64_t h = 0;
+            if (formula) h = formula_hash(lm.st);
+            const float *ep = B.evalP + (size_t)slot * g.AS;
+            for (int i = lane; i < A; i += WAVE) {
+                float p = formula ? formula_p(h, i, ev) : ep[i];
+                ldsf[i] = p * (gs_valid(g, lm.st, i) ? 1.0f : 0.0f); // child_priors * valid
+            }
+            __syncthreads();
+            float s = np_pairwise_sum<float>(ldsf, A, lane);
+            const bool renorm = (s > 0.0f) && (s != 1.0f);
+            for (int i = lane; i < A; i += WAVE)
+                Prow[i] = renorm ? ldsf[i] / s : ldsf[i];
+            v = formula ? formula_v(h, ev) : B.evalV[slot];
         }
-        __syncthreads();
-        float s = np_pairwise_sum<float>(ldsf, A, lane);
-        const bool renorm = (s > 0.0f) && (s != 1.0f);
-        for (int i = lane; i < A; i += WAVE)
-            Prow[i] = renorm ? ldsf[i] / s : ldsf[i];
-        v = formula ? formula_v(h, ev) : B.evalV[slot];
+        if (B.tt && !formula && lane == 0) {
+            nd[12] = __float_as_uint(v); // a later twin reads the value here
+            if (hit < 0) {
+                // insert: first empty / stale-epoch / same-tag entry of the probe window, else a hash-chosen victim
+                const uint64_t h = formula_hash(lm.st);
+                unsigned long long *tt = B.tt + (size_t)slot * ((size_t)B.tt_mask + 1);
+                const unsigned ep = tt_epoch_byte(S->tt_epoch);
+                int victim = (int)((h >> 20) & (TT_PROBES - 1));
+                for (int q = TT_PROBES - 1; q >= 0; q--) {
+                    const unsigned long long e0 = tt[((unsigned)h + (unsigned)q) & (unsigned)B.tt_mask];
+                    if (e0 == 0ull || ((unsigned)(e0 >> 32) & 0xFFu) != ep || (e0 >> 40) == (h >> 40)) victim = q;
+                }
+                tt[((unsigned)h + (unsigned)victim) & (unsigned)B.tt_mask] = tt_entry(h, ep, leaf);
+            }
+        }
     } else {
         v = (float)lm.result; // get_result(), python int
     }
@@ -710,7 +771,8 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
         S->n_search += 1;
         S->sum_path += plen;
         S->n_term += term;
-        S->n_eval += 1 - term;
+        S->n_eval += (term || hit >= 0) ? 0 : 1;
+        S->n_hit += hit >= 0 ? 1 : 0;
     }
     if (phase == PH_EXPAND_ROOT) {
         root_prep(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
@@ -834,6 +896,24 @@ __device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32
         S->n_nodes = kept;
         S->deepness_correction = child_deep;
         S->tree_size = carried;
+        if (B.tt) {
+            // the kept nodes were renumbered: enter the expanded ones into the table under the new epoch (one node
+            // per lane; two lanes racing for one entry just leave one of them cached)
+            const unsigned ep = tt_epoch_byte(S->tt_epoch + 1);
+            unsigned long long *tt = B.tt + (size_t)slot * ((size_t)B.tt_mask + 1);
+            for (int j = lane; j < kept; j += WAVE) {
+                const NodeMeta km = load_meta(pool, g, j);
+                if ((km.flags & NF_EXPANDED) && !(km.flags & NF_TERMINAL)) {
+                    const uint64_t h = formula_hash(km.st);
+                    int victim = (int)((h >> 20) & (TT_PROBES - 1));
+                    for (int q = TT_PROBES - 1; q >= 0; q--) {
+                        const unsigned long long e0 = tt[((unsigned)h + (unsigned)q) & (unsigned)B.tt_mask];
+                        if (e0 == 0ull || ((unsigned)(e0 >> 32) & 0xFFu) != ep) victim = q;
+                    }
+                    tt[((unsigned)h + (unsigned)victim) & (unsigned)B.tt_mask] = tt_entry(h, ep, j);
+                }
+            }
+        }
     } else if (reuse) {
         // children[move] did not exist: a fresh, unexpanded node becomes the root
         init_node(pool, g, 0, st, -1, move, child_deep, lane);
@@ -854,6 +934,7 @@ __device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32
     S->root_prior_f64 = 0;
     S->max_deepness = 0;
     S->terminal_count = 0;
+    S->tt_epoch = S->tt_epoch + 1; // node indices changed: every table entry of this game is now stale
     __syncthreads();
     return 0;
 }
@@ -904,6 +985,7 @@ __device__ void fresh_game(const Geo &g, const SearchCfg &cfg, const TreeBufs &B
     S->game_idx = game_idx;
     S->temperature = 1.0;
     S->phase = PH_IDLE;
+    S->tt_epoch = S->tt_epoch + 1;
     (void)plies;
     __syncthreads();
 }

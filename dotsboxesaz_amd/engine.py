@@ -30,7 +30,7 @@ class Engine:
 
     def __init__(self, rows, cols, n_slots, mcts_num_read=800, cpuct=(1.25, 19652), noise=(0.0, 0.0),
                  temperature=None, reuse_tree=True, evaluator="formula", nodes_per_slot=0, seed=0, device=0,
-                 max_out_rows=0, nn_precision=0, match_play=False, evaluator2="formula"):
+                 max_out_rows=0, nn_precision=0, match_play=False, evaluator2="formula", transposition_cache=True):
         self._L = _lib.load()
         self.rows, self.cols = int(rows), int(cols)
         self.H, self.W = self.rows + 1, self.cols + 1
@@ -53,6 +53,7 @@ class Engine:
         cfg.nn_precision = int(nn_precision)
         cfg.match_play = int(bool(match_play))
         cfg.evaluator2 = self.EVALUATORS[evaluator2] if isinstance(evaluator2, str) else int(evaluator2)
+        cfg.transposition_cache = 0 if transposition_cache else 1
         self.cfg = cfg
         self._drained = []
         self.h = C.c_void_p()

@@ -70,6 +70,9 @@ typedef struct {
     int32_t match_play;     /* two-model match play (self_play.compute_elo, :309-344): the evaluator of a move's
                                search is model (root.to_play XOR game_idx&1) */
     int32_t evaluator2;     /* DBAZ_EVAL_* of model 1 (match play) */
+    int32_t transposition_cache; /* 0 = on for network evaluators (default), 1 = off.  The reference caches (p, v) by
+                             * position hash (utils/proxies.py:35-43); results are identical either way */
+    int32_t reserved0;
 } dbaz_config;
 
 typedef struct {
@@ -90,6 +93,7 @@ typedef struct {
     double ms_total, ms_tree, ms_nn;
     int64_t nn_launches;    /* conv-tower launches inside the timed region */
     double ms_nn_tower;     /* summed duration of the dominant conv kernel */
+    int64_t cache_hits;     /* leaves whose (p, v) came from an already evaluated twin position of the same tree */
 } dbaz_counters;
 
 const char *dbaz_last_error(const dbaz_engine *e); /* e may be NULL: error of the last dbaz_create */
