@@ -304,3 +304,31 @@ def test_baseline_config0_reference_game_with_recorded_network_outputs():
     z = np.where(g[name + "_player"] == winner, st["result"][0], -st["result"][0])
     assert np.array_equal(z, g[name + "_z"])
     e.close()
+
+
+# ---------------------------------------------------------------- transposition cache (B1)
+@pytest.mark.parametrize("rows,cols,sims,precision", [(3, 3, 60, 0), (6, 6, 120, 1)])
+def test_transposition_cache_is_transparent(rows, cols, sims, precision):
+    """Per-game transposition table (utils/proxies.py:35-43 semantics): the same seeded self-play with the cache on
+    and off produces identical rows; every hit replaces exactly one network evaluation."""
+    import torch
+    from dotsboxesaz_amd.engine import Engine
+    from dotsboxesaz_amd import nn as dnn
+    torch.manual_seed(3)
+    model = dnn.ResNetZero(dnn.resnet_params(rows, cols, 32, 2, 4, 8))
+    out = []
+    for cache in (True, False):
+        e = Engine(rows, cols, 24, mcts_num_read=sims, noise=(0.8, 0.25), reuse_tree=True, evaluator="resnet", seed=5,
+                   nn_precision=precision, transposition_cache=cache)
+        e.load_state_dict(model.state_dict(), "resnet", **model.shape)
+        e.selfplay_start(24, 0)
+        e.run()
+        c = e.counters()
+        out.append((e.fetch_samples(), c))
+        e.close()
+    (a, ca), (b, cb) = out
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert ca["expansions"] == cb["expansions"] and ca["terminal_leaves"] == cb["terminal_leaves"]
+    assert cb["cache_hits"] == 0 and ca["cache_hits"] > 0.05 * ca["expansions"]
+    assert ca["nn_evals"] + ca["cache_hits"] == cb["nn_evals"]
