@@ -236,7 +236,8 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     B.tt_mask = 0;
     {
         auto nn_ev = [](int ev) { return ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN; };
-        if (cfg->transposition_cache == 0 && (nn_ev(cfg->evaluator) || (cfg->match_play && nn_ev(cfg->evaluator2)))) {
+        // off in two-model match play, like the reference (self_play.py:230): a kept twin may belong to the other model
+        if (cfg->transposition_cache == 0 && !cfg->match_play && nn_ev(cfg->evaluator)) {
             size_t tcap = 64;
             while (tcap < 2 * (size_t)g.cap) tcap <<= 1; // <= 50 % load even when every node of the pool is a distinct position
             CREATE_CHECK(dmalloc(e, &B.tt, ns * tcap));
