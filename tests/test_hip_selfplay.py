@@ -307,7 +307,7 @@ def test_baseline_config0_reference_game_with_recorded_network_outputs():
 
 
 # ---------------------------------------------------------------- transposition cache (B1)
-@pytest.mark.parametrize("rows,cols,sims,precision", [(3, 3, 60, 0), (6, 6, 120, 1)])
+@pytest.mark.parametrize("rows,cols,sims,precision", [(3, 3, 60, 0), (6, 6, 120, 1), (9, 9, 40, 1), (2, 5, 80, 1)])
 def test_transposition_cache_is_transparent(rows, cols, sims, precision):
     """Per-game transposition table (utils/proxies.py:35-43 semantics): the same seeded self-play with the cache on
     and off produces identical rows; every hit replaces exactly one network evaluation."""
@@ -330,5 +330,5 @@ def test_transposition_cache_is_transparent(rows, cols, sims, precision):
     for k in a:
         assert np.array_equal(a[k], b[k]), k
     assert ca["expansions"] == cb["expansions"] and ca["terminal_leaves"] == cb["terminal_leaves"]
-    assert cb["cache_hits"] == 0 and ca["cache_hits"] > 0.05 * ca["expansions"]
+    assert cb["cache_hits"] == 0 and ca["cache_hits"] > 0.01 * ca["expansions"]
     assert ca["nn_evals"] + ca["cache_hits"] == cb["nn_evals"]
