@@ -75,7 +75,7 @@ struct NNState {
     float *sn_w1 = nullptr, *sn_b1 = nullptr, *sn_ps1 = nullptr, *sn_pt1 = nullptr; // fc1
     size_t sn_lds = 0;
     int S = 1, NT = 1, NTT = 7;                 // samples / position tiles per conv workgroup (NTT: compiled tile count)
-    int S_small = 0, S_mid = 0, cus = 256;      // tail launches: samples per workgroup of the <2,2> / <4,4> variants (0: unused)
+    int S_small = 0, S_mid = 0, S_big = 0, cus = 256; // tail launches: samples per workgroup of the <2,2> / <4,4> / <5,5> variants (0: unused)
     size_t conv_lds = 0;
 };
 
@@ -422,7 +422,7 @@ struct TowerArgs {
     int *overflow;
     int S, nblocks, hc;
     // tail handling (see nn_forward): role 0 = main launch, 1 / 2 = tail launches with fewer samples per workgroup
-    int role, S_main, S_small, S_mid, cus;
+    int role, S_main, S_small, S_mid, S_big, cus;
     unsigned long long *stamp_out; // diagnostic build only
 };
 
@@ -446,6 +446,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         int mode = 0;
         if (tail > 0 && a.S_small > 0 && tail <= a.cus * a.S_small) mode = 1;
         else if (tail > 0 && a.S_mid > 0 && tail <= a.cus * a.S_mid) mode = 2;
+        else if (tail > 0 && a.S_big > 0 && tail <= a.cus * a.S_big) mode = 3;
         if (a.role == 0) {
             if (mode) limit = n_full;
         } else {
@@ -1279,10 +1280,11 @@ static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, 
     switch (ntt) {
     case 2: return tower_inst<C, 2, 2>(nn, s, ta, grid, attr_only);
     case 4: return tower_inst<C, 4, 4>(nn, s, ta, grid, attr_only);
+    case 5: return tower_inst<C, 5, 5>(nn, s, ta, grid, attr_only);
     default: return tower_inst<C, 7, 6>(nn, s, ta, grid, attr_only);
     }
 }
-// ntt: tiles per wave of the instantiation (7 -> <7,6>, 4 -> <4,4>, 2 -> <2,2>)
+// ntt: tiles per wave of the instantiation (7 -> <7,6>, 5 -> <5,5>, 4 -> <4,4>, 2 -> <2,2>)
 static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const TowerArgs &ta, int ntt, int grid, bool attr_only)
 {
     switch (nn->C) {
@@ -1612,11 +1614,13 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     nn->NT = (S * HW + 15) / 16;
     nn->conv_lds = lds_bytes(S);
     nn->NTT = nn->NT > 8 ? 7 : (nn->NT > 4 ? 4 : 2); // tiles per wave; two waves cover 2*NTT >= NT tiles
-    // tail variants: <2,2> holds 64 rows, <4,4> 128 rows
-    nn->S_small = nn->S_mid = 0;
+    // tail variants: <2,2> holds 64 rows, <4,4> 128 rows, <5,5> 160 rows
+    nn->S_small = nn->S_mid = nn->S_big = 0;
     if (nn->NTT == 7) {
-        nn->S_mid = std::min(128 / HW, nn->S - 1);
+        nn->S_big = std::min(160 / HW, nn->S - 1);
+        nn->S_mid = std::min(128 / HW, nn->S_big - 1);
         nn->S_small = std::min(64 / HW, nn->S_mid - 1);
+        if (nn->S_big < 0) nn->S_big = 0;
     } else if (nn->NTT == 4) {
         nn->S_small = std::min(64 / HW, nn->S - 1);
     }
@@ -1630,6 +1634,7 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true);
     if (he == hipSuccess && nn->S_mid > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 4, 0, true);
     if (he == hipSuccess && nn->S_small > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 2, 0, true);
+    if (he == hipSuccess && nn->S_big > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 5, 0, true);
     if (he != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(he); return DBAZ_EDEVICE; }
     nn->ready = true;
     return DBAZ_OK;
@@ -1672,7 +1677,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     ta.overflow = nn->overflow; ta.S = nn->S; ta.nblocks = nn->blocks; ta.hc = hc;
     ta.stamp_out = nn->stamp_out;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.cus = nn->cus;
+    ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.S_big = nn->S_big; ta.cus = nn->cus;
     ta.role = 0; ta.S = nn->S;
     (void)tower_dispatch(nn, s, ta, nn->NTT, (max_n + nn->S - 1) / nn->S, false);
     if (nn->S_small > 0) { // tail <= cus * S_small samples: one round of <2,2> workgroups
@@ -1682,6 +1687,10 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     if (nn->S_mid > 0) {   // tail <= cus * S_mid samples: one round of <4,4> workgroups
         ta.role = 2; ta.S = nn->S_mid;
         (void)tower_dispatch(nn, s, ta, 4, nn->cus, false);
+    }
+    if (nn->S_big > 0) {   // tail <= cus * S_big samples: one round of <5,5> workgroups
+        ta.role = 3; ta.S = nn->S_big;
+        (void)tower_dispatch(nn, s, ta, 5, nn->cus, false);
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
     HeadArgs ha;
