@@ -45,6 +45,7 @@ enum Phase : int32_t {
 
 struct Slot {
     int32_t phase;
+    int32_t ready_at;        // engine step at which k_expand_backup set PH_READY (same 8-byte word as phase, written together)
     int32_t n_nodes;
     int32_t sims_left;
     int32_t root_N;          // TreeRoot.child_number_visits[move]
@@ -65,6 +66,8 @@ struct Slot {
     int32_t leaf_hit;        // transposition cache: expanded node of this tree with the leaf's position, or -1
     int32_t tt_epoch;        // 1..255, bumped at every re-root / new game (stale table entries are preferred victims)
     int64_t n_hit;
+    int32_t sel_step;        // engine step of the k_select that left the current leaf (k_expand_backup takes only those)
+    int32_t pad0;
 };
 
 struct PathEnt {
@@ -94,6 +97,7 @@ struct SearchCfg {
     int evaluator2;          // evaluator of model 1
     uint64_t seed;
     int table_n;             // entries in pbc/sqrt tables
+    int step;                // engine step counter of this launch
 };
 
 // device buffer bundle handed to the tree kernels
@@ -111,6 +115,8 @@ struct TreeBufs {
     int32_t *eval_list2;// [n_slots] same for model 1 (match play)
     int32_t *n_eval;   // [2] list lengths
     int32_t *remap;    // [n_slots][cap] compaction scratch
+    int32_t *drv_list;  // [n_slots] slots that need the driver this step (k_driver_scan)
+    int32_t *drv_count; // [1]
     unsigned long long *tt; // [n_slots][tt_mask+1] transposition table (tag24 | epoch8 | node index), nullptr = off
     int32_t tt_mask;
     const double *pbc_table;  // log((N+base+1)/base)+cpuct for N < table_n (host libm)

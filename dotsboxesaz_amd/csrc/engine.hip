@@ -26,6 +26,8 @@ struct dbaz_engine {
     TreeBufs B;
     int n_slots = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // re-rooting / game turnover (k_advance_auto) runs here, next to the network
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     std::vector<void *> allocs;
     NNState *nn = nullptr;   // the model that dbaz_nn_* calls address (nns[cur_model])
@@ -190,6 +192,9 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     } while (0)
     CREATE_HIP(hipSetDevice(cfg->device));
     CREATE_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CREATE_HIP(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    CREATE_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    CREATE_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     CREATE_HIP(hipEventCreate(&e->ev_t0));
     CREATE_HIP(hipEventCreate(&e->ev_t1));
 
@@ -232,6 +237,8 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     CREATE_CHECK(dmalloc(e, &B.eval_list2, ns));
     CREATE_CHECK(dmalloc(e, &B.n_eval, 4));
     CREATE_CHECK(dmalloc(e, &B.remap, ns * g.cap, false));
+    CREATE_CHECK(dmalloc(e, &B.drv_list, ns));
+    CREATE_CHECK(dmalloc(e, &B.drv_count, 4));
     B.tt = nullptr;
     B.tt_mask = 0;
     {
@@ -286,6 +293,7 @@ extern "C" void dbaz_destroy(dbaz_engine *e)
 {
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     for (int i = 0; i < 2; i++) if (e->nns[i]) nn_destroy(e->nns[i]);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stage) (void)hipFree(e->stage);
@@ -294,6 +302,9 @@ extern "C" void dbaz_destroy(dbaz_engine *e)
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ev_t0) (void)hipEventDestroy(e->ev_t0);
     if (e->ev_t1) (void)hipEventDestroy(e->ev_t1);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -525,7 +536,18 @@ static int sim_step(dbaz_engine *e, bool with_driver)
     const bool use_nn = is_nn(e->sc.evaluator);
     const bool use_nn2 = e->sc.match_play && is_nn(e->sc.evaluator2);
     if (use_nn || use_nn2) HIP_CHECK_RET(e, hipMemsetAsync(e->B.n_eval, 0, 8, s));
+    e->sc.step = (int)(e->steps & 0x3FFFFFFF) + 1; // never 0 (a fresh Slot's stamp)
     tree_launch_select(s, e->g, e->sc, e->B, e->n_slots);
+    if (with_driver) {
+        // The driver step (move choice, re-rooting with subtree compaction, game turnover) only touches slots whose
+        // reads are done (PH_READY / PH_EMIT); the rest of this step only touches slots that are searching.  A slot's
+        // compaction is one wave working for up to a millisecond, so it runs on a second stream NEXT TO the network
+        // instead of holding up every game; the streams join before the next select.
+        HIP_CHECK_RET(e, hipEventRecord(e->ev_fork, s));
+        HIP_CHECK_RET(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        tree_launch_advance_auto(e->stream2, e->g, e->sc, e->B, e->n_slots);
+        HIP_CHECK_RET(e, hipEventRecord(e->ev_join, e->stream2));
+    }
     if (use_nn) {
         hipEvent_t a = nullptr, b = nullptr;
         if (e->timing) { a = next_event(e); b = next_event(e); }
@@ -537,7 +559,7 @@ static int sim_step(dbaz_engine *e, bool with_driver)
         e->nn_launches++;
     }
     tree_launch_expand_backup(s, e->g, e->sc, e->B, e->n_slots);
-    if (with_driver) tree_launch_advance_auto(s, e->g, e->sc, e->B, e->n_slots);
+    if (with_driver) HIP_CHECK_RET(e, hipStreamWaitEvent(s, e->ev_join, 0));
     e->steps++;
     HIP_CHECK_RET(e, hipGetLastError());
     return DBAZ_OK;
@@ -634,6 +656,7 @@ extern "C" int dbaz_select(dbaz_engine *e, int32_t *n_active, int16_t *leaf_x, u
     int16_t *d_x = cv.take<int16_t>(ns * F);
     uint8_t *d_ne = cv.take<uint8_t>(ns);
     int32_t *d_na = cv.take<int32_t>(4);
+    e->sc.step = (e->sc.step & 0x3FFFFFFF) + 1;
     tree_launch_select(e->stream, g, e->sc, e->B, e->n_slots);
     HIP_CHECK_RET(e, hipMemsetAsync(d_na, 0, 16, e->stream));
     tree_launch_get_leaves(e->stream, g, e->B, e->n_slots, d_x, d_ne, d_na);

@@ -611,6 +611,7 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
         pe.node = cur; pe.move_in = (int16_t)in_move; pe.to_play = (int16_t)m.st.to_play;
         path[depth] = pe;
         S->leaf = cur;
+        S->sel_step = cfg.step;
         S->path_len = depth + 1;
         S->leaf_terminal = (m.flags & NF_TERMINAL) ? 1 : 0;
         S->leaf_result = m.result;
@@ -680,6 +681,13 @@ __global__ void __launch_bounds__(WAVE * SELECT_WAVES) k_select(Geo g, SearchCfg
     if (my >= 0) (model ? B.eval_list2 : B.eval_list)[s_base[model] + my] = slot;
 }
 
+// phase and the step stamp leave in ONE 8-byte store: the driver kernel runs on a second stream next to this step's
+// expand/backup and must not take a slot that turned PH_READY during the very step it is running in
+__device__ __forceinline__ void set_phase_stamped(Slot *S, int phase, int step)
+{
+    *reinterpret_cast<volatile unsigned long long *>(&S->phase) = (unsigned long long)(unsigned)phase | ((unsigned long long)(unsigned)step << 32);
+}
+
 // ------------------------------------------------------------------------------------
 // _search tail: prior masking (mcts.py:189-196), expand (:116-119), backup (:121-132)
 // ------------------------------------------------------------------------------------
@@ -691,6 +699,10 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
     Slot *S = B.slots + slot;
     const int phase = S->phase;
     if (phase != PH_EXPAND_ROOT && phase != PH_SIMS)
+        return;
+    // only slots for which THIS step's k_select left a leaf: the driver kernel (second stream) may have started a new
+    // search in a slot while this step's network was running
+    if (S->sel_step != cfg.step)
         return;
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
     const PathEnt *path = B.path + (size_t)slot * g.dmax;
@@ -776,11 +788,11 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
     }
     if (phase == PH_EXPAND_ROOT) {
         root_prep(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
-        if (lane == 0) S->phase = S->sims_left > 0 ? PH_SIMS : PH_READY;
+        if (lane == 0) set_phase_stamped(S, S->sims_left > 0 ? PH_SIMS : PH_READY, cfg.step);
     } else if (lane == 0) {
         int left = S->sims_left - 1;
         S->sims_left = left;
-        if (left <= 0) S->phase = PH_READY;
+        if (left <= 0) set_phase_stamped(S, PH_READY, cfg.step);
     }
 }
 
@@ -825,42 +837,72 @@ __device__ int compact_subtree(const Geo &g, uint32_t *pool, int32_t *remap, uin
     }
     __syncthreads();
     __threadfence_block();
-    // pass 2: move kept nodes (ascending), fixing parent and child indices
+    // pass 2: move kept nodes (ascending), fixing parent and child indices.  CB nodes per iteration: ALL their
+    // dwords and remap look-ups are in flight together (one wave, so memory latency is the whole cost), and nothing is
+    // stored before every source of the batch has been read -- a destination (rank r) never lies above its source, so
+    // within a batch only sources of that batch can be overwritten, and later kept nodes sit above every destination.
     const int ndw = g.node_dw;
     const int c_lo = META_DW + 3 * g.AS, c_hi = META_DW + 4 * g.AS;
-    for (int base = newroot; base < n_nodes; base += WAVE) {
-        uint64_t bal = marks[(base - newroot) >> 6];
-        while (bal) {
-            int b = __ffsll((long long)bal) - 1;
-            bal &= bal - 1;
-            int k = base + b;
-            int j = remap[k];
-            const uint32_t *src = node_ptr(pool, g, k);
-            uint32_t *dst = node_ptr(pool, g, j);
-            for (int dw0 = 0; dw0 < ndw; dw0 += 4 * WAVE) {
-                uint32_t v[4];
-                int dws[4];
+    constexpr int CB = 8;          // nodes per batch
+    constexpr int CD = 8;          // dwords per lane per node (node_dw <= 64 * CD = 512: A <= 124; larger boards loop)
+    int base = newroot;
+    uint64_t bal = base < n_nodes ? marks[0] : 0ull;
+    for (;;) {
+        int ks[CB], nb = 0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    int dw = dw0 + u * WAVE + lane;
-                    dws[u] = dw;
-                    v[u] = dw < ndw ? src[dw] : 0u;
-                }
+        for (int q = 0; q < CB; q++) { // next kept node indices (wave-uniform bookkeeping, constant subscripts only)
+            ks[q] = -1;
+            while (!bal && base + WAVE < n_nodes) {
+                base += WAVE;
+                bal = marks[(base - newroot) >> 6];
+            }
+            if (bal) {
+                const int b = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                ks[q] = base + b;
+                nb = q + 1;
+            }
+        }
+        if (nb == 0) break;
+        for (int dw0 = 0; dw0 < ndw; dw0 += CD * WAVE) {
+            uint32_t v[CB][CD];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    int dw = dws[u];
-                    if (dw < ndw) {
-                        if (dw == 8)
-                            v[u] = (k == newroot) ? 0xFFFFFFFFu : (uint32_t)remap[(int)v[u]];
-                        else if (dw >= c_lo && dw < c_hi && (int)v[u] >= 0)
-                            v[u] = (uint32_t)remap[(int)v[u]];
+            for (int q = 0; q < CB; q++)
+                if (q < nb) {
+                    const uint32_t *src = node_ptr(pool, g, ks[q]);
+#pragma unroll
+                    for (int u = 0; u < CD; u++) {
+                        const int dw = dw0 + u * WAVE + lane;
+                        v[q][u] = dw < ndw ? src[dw] : 0u;
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (dws[u] < ndw) dst[dws[u]] = v[u];
-            }
+            for (int q = 0; q < CB; q++)
+                if (q < nb) {
+#pragma unroll
+                    for (int u = 0; u < CD; u++) {
+                        const int dw = dw0 + u * WAVE + lane;
+                        if (dw < ndw) {
+                            if (dw == 8)
+                                v[q][u] = (ks[q] == newroot) ? 0xFFFFFFFFu : (uint32_t)remap[(int)v[q][u]];
+                            else if (dw >= c_lo && dw < c_hi && (int)v[q][u] >= 0)
+                                v[q][u] = (uint32_t)remap[(int)v[q][u]];
+                        }
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < CB; q++)
+                if (q < nb) {
+                    uint32_t *dst = node_ptr(pool, g, remap[ks[q]]);
+#pragma unroll
+                    for (int u = 0; u < CD; u++) {
+                        const int dw = dw0 + u * WAVE + lane;
+                        if (dw < ndw) dst[dw] = v[q][u];
+                    }
+                }
+            if (dw0 + CD * WAVE < ndw) __threadfence_block(); // (boards with more than 512 dwords per node)
         }
+        if (nb < CB) break;
     }
     __syncthreads();
     return kept;
@@ -1139,15 +1181,17 @@ __global__ void __launch_bounds__(WAVE) k_selfplay_start(Geo g, SearchCfg cfg, T
 
 // One pass of the driver for every slot whose reads are done (PH_READY) or whose finished
 // game still waits for output space (PH_EMIT).
-__global__ void __launch_bounds__(WAVE) k_advance_auto(Geo g, SearchCfg cfg, TreeBufs B)
+// (the slots come from k_driver_scan's list: a step in which no slot needs the driver costs two tiny launches instead
+// of one workgroup per game squeezing in between the network's workgroups)
+__device__ void advance_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, float *ldsf, double *ldsd,
+                            uint64_t *marks, int lane)
 {
-    __shared__ float ldsf[DBAZ_MAX_A];
-    __shared__ double ldsd[DBAZ_MAX_A];
-    extern __shared__ uint64_t marks[];
-    const int slot = blockIdx.x, lane = threadIdx.x;
     Slot *S = B.slots + slot;
-    const int phase = S->phase;
+    const unsigned long long pw = *reinterpret_cast<volatile const unsigned long long *>(&S->phase); // phase | ready_at << 32
+    const int phase = (int)(unsigned)pw, ready_at = (int)(unsigned)(pw >> 32);
     if (phase != PH_READY && phase != PH_EMIT)
+        return;
+    if (phase == PH_READY && ready_at == cfg.step) // became ready in THIS step: its expand/backup wave may still be writing
         return;
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
     const int A = g.A, F = 3 * g.HW, rcap = g.E + 1;
@@ -1249,6 +1293,37 @@ __global__ void __launch_bounds__(WAVE) k_advance_auto(Geo g, SearchCfg cfg, Tre
         return;
     }
     start_move_search(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
+}
+
+// which slots need the driver: finished reads (not of this very step, see set_phase_stamped) or a blocked emit
+__global__ void __launch_bounds__(256) k_driver_scan(SearchCfg cfg, TreeBufs B, int n_slots)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool need = false;
+    if (i < n_slots) {
+        const unsigned long long pw = *reinterpret_cast<volatile const unsigned long long *>(&B.slots[i].phase);
+        const int phase = (int)(unsigned)pw, ready_at = (int)(unsigned)(pw >> 32);
+        need = phase == PH_EMIT || (phase == PH_READY && ready_at != cfg.step);
+    }
+    const unsigned long long m = __ballot(need);
+    const int lane = threadIdx.x & (WAVE - 1);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(B.drv_count, (int)__popcll(m));
+    base = __shfl(base, 0);
+    if (need) B.drv_list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+__global__ void __launch_bounds__(WAVE) k_advance_auto(Geo g, SearchCfg cfg, TreeBufs B)
+{
+    __shared__ float ldsf[DBAZ_MAX_A];
+    __shared__ double ldsd[DBAZ_MAX_A];
+    extern __shared__ uint64_t marks[];
+    const int lane = threadIdx.x;
+    const int n = *B.drv_count;
+    for (int li = blockIdx.x; li < n; li += gridDim.x) {
+        advance_one(g, cfg, B, B.drv_list[li], ldsf, ldsd, marks, lane);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1419,7 +1494,9 @@ void tree_launch_selfplay_start(hipStream_t s, const Geo &g, const SearchCfg &c,
 }
 void tree_launch_advance_auto(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
 {
-    hipLaunchKernelGGL(k_advance_auto, dim3(n_slots), dim3(WAVE), marks_bytes(g), s, g, c, B);
+    (void)hipMemsetAsync(B.drv_count, 0, 4, s);
+    hipLaunchKernelGGL(k_driver_scan, dim3((n_slots + 255) / 256), dim3(256), 0, s, c, B, n_slots);
+    hipLaunchKernelGGL(k_advance_auto, dim3(n_slots < 128 ? n_slots : 128), dim3(WAVE), marks_bytes(g), s, g, c, B);
 }
 void tree_launch_get_roots(hipStream_t s, const Geo &g, const TreeBufs &B, int n_slots, double *priors, float *tv,
                            int32_t *nv, int32_t *changed, int32_t *stats, float *q, float *root_tv, int32_t *root_nv,
