@@ -332,3 +332,28 @@ def test_transposition_cache_is_transparent(rows, cols, sims, precision):
     assert ca["expansions"] == cb["expansions"] and ca["terminal_leaves"] == cb["terminal_leaves"]
     assert cb["cache_hits"] == 0 and ca["cache_hits"] > 0.01 * ca["expansions"]
     assert ca["nn_evals"] + ca["cache_hits"] == cb["nn_evals"]
+
+
+def test_rows_do_not_depend_on_slot_scheduling():
+    """A game's rows are a function of (seed, game_idx) only: 96 games played on 24 slots (refills; games drift apart,
+    the driver kernel re-roots some slot next to almost every network launch) equal the same 96 games played on 96
+    slots in lockstep."""
+    import torch
+    from dotsboxesaz_amd.engine import Engine
+    from dotsboxesaz_amd import nn as dnn
+    torch.manual_seed(4)
+    model = dnn.ResNetZero(dnn.resnet_params(3, 3, 32, 2, 4, 8))
+    out = []
+    for n_slots in (24, 96):
+        e = Engine(3, 3, n_slots, mcts_num_read=48, noise=(0.8, 0.25), reuse_tree=True, evaluator="resnet", seed=11)
+        e.load_state_dict(model.state_dict(), "resnet", **model.shape)
+        e.selfplay_start(96, 0)
+        e.run()
+        c = e.counters()
+        assert c["games_finished"] == 96 and c["error_slots"] == 0
+        out.append(e.fetch_samples())
+        e.close()
+    a, b = out
+    assert len(a["z"]) == len(b["z"])
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
