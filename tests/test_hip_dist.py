@@ -69,3 +69,23 @@ def test_bench_under_torch_distributed_run():
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["replay_allgather"]["rows"] == 256 * 8
     assert np.isfinite(d["roofline"]["frac"])
+
+
+def _bench(*flags):
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + list(flags), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_full_games_mode():
+    d = _bench("--full-games", "48", "--slots", "16", "--board", "3", "--sims", "20", "--channels", "32", "--blocks", "2")
+    assert d["metric"] == "selfplay_games_per_sec" and d["games"] == 48 and d["value"] > 0
+    assert d["rows"] >= 48 * 8 and 0.0 <= d["cache_hit_fraction"] < 1.0
+
+
+def test_bench_train_data_mode():
+    d = _bench("--train-data", "50000", "--board", "6")
+    assert d["metric"] == "train_data_rows_per_sec" and d["value"] > 0
+    assert d["build_pos_average"]["rows_out"] < d["build_raw"]["rows_out"] == 50000
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
