@@ -175,7 +175,7 @@ def test_dataset_errors():
     e = _engine(3, 3)
     rows = torch.tensor(pack_rows(G["ds_x"], G["ds_visits"], G["ds_z"])).cuda()
     with pytest.raises(DbazError):
-        e.dataset_fetch_guard = e.dataset_batch([0], 0)          # no dataset yet
+        e.dataset_batch([0], 0)                                  # no dataset yet
     e.dataset_begin()
     with pytest.raises(DbazError):
         e.dataset_add_rows((rows.data_ptr(), rows.shape[0], rows.shape[1] - 8))   # wrong row size
