@@ -228,9 +228,13 @@ def train_data_bench(args, local_rank, torch):
     out["batch"] = res
     big = res["262144"]
     out["value"] = big["rows_per_sec"]
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "r01_pmc_train_data.json")
+    if os.path.exists(pmc) and (args.board, n) == (6, 2000000):
+        traffic = json.load(open(pmc))["kernels"].get("k_make_batch", {}).get("traffic_bytes_max_launch")
     out["roofline"] = {"bound": "hbm", "kernel": "k_make_batch (gather + symmetry LUT, one wave per row)",
                        "achieved": big["GBps_algorithmic"], "peak": 8000.0, "unit": "GB/s", "frac": big["GBps_algorithmic"] / 8000.0,
-                       "traffic": None, "note": "wall clock per call incl. index upload, allocation of the output tensors and the "
+                       "traffic": traffic, "algorithmic_bytes_per_launch": 262144 * ((2 * F + 4 * A + 4) + (4 * F + 4 * A + 4)), "note": "wall clock per call incl. index upload, allocation of the output tensors and the "
                                                 "stream sync that orders the batch before torch"}
     print(json.dumps(out), flush=True)
     e.close()
