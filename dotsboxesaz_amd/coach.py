@@ -63,7 +63,6 @@ class Coach:
 
     def selfplay(self, generation):
         """coach.selfplay (coach.py:17-32) -> self_play.generate_games, rows kept in HBM."""
-        import torch
         model = self.model_class(self.params)
         if generation != 0:
             model.load_parameters(generation - 1)
@@ -73,19 +72,7 @@ class Coach:
         rank, world = (self.dist.get_rank(), self.dist.get_world_size()) if self.dist is not None else (0, 1)
         first, count = sp.shard_games(n_games, world, rank)
         tick = time.time()
-        e.selfplay_start(count, first)
-        chunks = []
-        while True:  # drain whenever the device row buffer fills (backpressure), keeping the rows on the device
-            e._ck(e._L.dbaz_run(e.h, 0))
-            ptr, n, rb = e.replay_rows_dev()
-            if n:
-                chunks.append(torch.as_tensor(sp._DevBuf(ptr, n * rb), device=torch.device("cuda", self.device)).view(n, rb).clone())
-            c = e.counters()
-            e.replay_rows_clear()
-            if c["active_slots"] == 0:
-                break
-        rows = torch.cat(chunks, dim=0) if chunks else torch.zeros((0, e.row_bytes), dtype=torch.uint8,
-                                                                   device=torch.device("cuda", self.device))
+        rows = sp.collect_rows_device(e, count, first)  # backpressure drains stay on the device
         if self.dist is not None and world > 1:
             rows, _ = sp.all_gather_rows(rows, self.dist)
         self.store.add_generation(generation, rows, train_split=float(_get(_get(_get(self.params, "nn"), "train_params"), "train_split", 0.9)))

@@ -106,12 +106,15 @@ def write_dataset(file_name, key, df):
 
 
 def generate_games(hdf_file_name, generation, nn_class, n_games, params, n_workers=None, games_per_workers=10,
-                   rows=None, cols=None, n_slots=None, device=0, dist=None):
+                   rows=None, cols=None, n_slots=None, device=0, dist=None, nn_precision=0):
     """Reference: self_play.generate_games (self_play.py:291-306) called from coach.selfplay
     (coach.py:27-29).  Plays n_games with generation-1's weights (random init for generation 0,
     self_play.py:187-190) and appends the samples (+ `training` = 0) to key "fresh".
     With torch.distributed initialised (one process per GPU) the game indices are sharded over
-    the ranks and the rows all-gathered; rank 0 writes."""
+    the ranks (the reference's np.array_split over pool workers, :294); every rank keeps its
+    finished rows on the device, the packed rows are all-gathered (RCCL; host-staged under gloo)
+    and EVERY rank builds the DataFrame of all n_games games -- the reference's workers all append
+    to the one HDF file (self_play.py:264-265); here rank 0 writes it."""
     from .engine import Engine
     game = _get(params, "game")
     if rows is None:
@@ -123,18 +126,22 @@ def generate_games(hdf_file_name, generation, nn_class, n_games, params, n_worke
     model = nn_class(params)
     if generation != 0:
         model.load_parameters(generation - 1)
-    eng = Engine(rows, cols, n_slots, evaluator=model.kind, device=device, seed=generation * 1000003 + rank,
-                 **engine_kwargs_from_params(params))
-    eng.load_state_dict(model.state_dict(), model.kind, **model.shape)
-    sp = SelfPlay(eng, params)
-    sp.play_games_sync(range(first, first + count))
-    if dist is not None and world > 1:
-        gather_replay(eng, dist)  # device-resident rows over RCCL; the host copy below is what gets written
-    df = sp.get_datasets(generation, True)
+    eng = Engine(rows, cols, n_slots, evaluator=model.kind, device=device, seed=generation * 1000003,  # Philox streams are keyed by (seed, game, ply): sharding does not change a game
+                
+                 nn_precision=nn_precision, **engine_kwargs_from_params(params))
+    try:
+        if model.kind in ("resnet", "simplenn"):
+            eng.load_state_dict(model.state_dict(), model.kind, **model.shape)
+        packed = collect_rows_device(eng, count, first)
+        if dist is not None and world > 1:
+            packed, _ = all_gather_rows(packed, dist)
+        samples = unpack_rows(packed.cpu().numpy(), eng.F, eng.A)
+    finally:
+        eng.close()
+    df = samples_to_dataframe(samples, generation, rows, cols, True)
     df["training"] = np.zeros(len(df.index), dtype=np.int8)
     if hdf_file_name is not None and rank == 0:
         write_dataset(hdf_file_name, "fresh", df)
-    eng.close()
     return df
 
 
@@ -147,10 +154,74 @@ class _DevBuf:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
 
 
+# RowMeta of csrc/common.h (28 bytes); a packed replay row is RowMeta | x int16[3HW] | visits int32[A], padded to 8 B
+ROW_META = np.dtype([("game_idx", "<i4"), ("move_idx", "<i2"), ("move", "<i2"), ("played", "<i2"),
+                     ("max_deepness", "<i2"), ("tree_size", "<i4"), ("terminal_count", "<i4"), ("q_value", "<f4"),
+                     ("player", "i1"), ("z", "i1"), ("pad", "<i2")])
+assert ROW_META.itemsize == 28
+
+
+def row_bytes(F, A):
+    return (ROW_META.itemsize + 2 * F + 4 * A + 7) // 8 * 8
+
+
+def unpack_rows(packed, F, A):
+    """Packed replay rows (uint8 [n, row_bytes], any rank order) -> the sample dict of
+    Engine.fetch_samples(), sorted by (game_idx, move_idx); pi = visits / (sum or 1.0) in float64
+    (self_play.py:114-115)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    n = packed.shape[0]
+    if n and packed.shape[1] != row_bytes(F, A):
+        raise ValueError("row stride %d does not match a %d-feature / %d-action board" % (packed.shape[1], F, A))
+    m0 = ROW_META.itemsize
+    meta = np.ascontiguousarray(packed[:, :m0]).view(ROW_META).reshape(n)
+    x = np.ascontiguousarray(packed[:, m0:m0 + 2 * F]).view("<i2").reshape(n, F)
+    vis = np.ascontiguousarray(packed[:, m0 + 2 * F:m0 + 2 * F + 4 * A]).view("<i4").reshape(n, A)
+    vs = vis.sum(axis=1, dtype=np.int64).astype(np.float64)
+    pi = vis.astype(np.float64) / np.where(vs == 0, 1.0, vs)[:, None]
+    out = dict(game_idx=meta["game_idx"].astype(np.int32), move_idx=meta["move_idx"].astype(np.int16),
+               move=meta["move"].astype(np.int16), player=meta["player"].astype(np.int8), x=x.astype(np.int16),
+               visits=vis.astype(np.int32), pi=pi, z=meta["z"].astype(np.int8),
+               max_deepness=meta["max_deepness"].astype(np.int16), tree_size=meta["tree_size"].astype(np.int32),
+               terminal_count=meta["terminal_count"].astype(np.int32), q_value=meta["q_value"].astype(np.float32),
+               played=meta["played"].astype(np.int16))
+    order = np.lexsort((out["move_idx"], out["game_idx"]))
+    return {k: v[order] for k, v in out.items()}
+
+
+def collect_rows_device(engine, count, first):
+    """Play games first .. first+count-1 and return their packed rows as ONE uint8 CUDA tensor
+    [n, row_bytes]; the rows never visit the host.  Whenever the device row buffer fills (the
+    engine's backpressure: finished games wait in PH_EMIT) its content is cloned on the device and
+    the buffer emptied."""
+    import torch
+    dev = torch.device("cuda", engine.cfg.device)
+    chunks = []
+    if count > 0:
+        engine.selfplay_start(count, first)
+        while True:
+            engine._ck(engine._L.dbaz_run(engine.h, 0))
+            ptr, n, rb = engine.replay_rows_dev()
+            if n:
+                chunks.append(torch.as_tensor(_DevBuf(ptr, n * rb), device=dev).view(n, rb).clone())
+            c = engine.counters()
+            engine.replay_rows_clear()
+            if c["active_slots"] == 0:
+                break
+    if chunks:
+        return torch.cat(chunks, dim=0)
+    return torch.zeros((0, engine.row_bytes), dtype=torch.uint8, device=dev)
+
+
 def all_gather_rows(rows, dist):
-    """rows: uint8 tensor [n_i, row_bytes] (any device).  Returns (uint8 [sum n_i, row_bytes], counts)."""
+    """rows: uint8 tensor [n_i, row_bytes] (any device).  Returns (uint8 [sum n_i, row_bytes], counts),
+    rank order.  Under RCCL ("nccl") the exchange runs device to device; a gloo group (CPU tests,
+    two ranks sharing one GPU) is staged through the host and the result returned on rows' device."""
     import torch
     world = dist.get_world_size()
+    home = rows.device
+    if rows.is_cuda and dist.get_backend() == "gloo":
+        rows = rows.cpu()
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
@@ -161,7 +232,7 @@ def all_gather_rows(rows, dist):
     out = torch.empty((world * mx, rows.shape[1]), dtype=torch.uint8, device=rows.device)
     dist.all_gather_into_tensor(out, padded)
     keep = torch.cat([out[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
-    return keep, counts
+    return keep.to(home), counts
 
 
 def gather_replay(engine, dist, synthetic_rows=0):

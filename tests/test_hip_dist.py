@@ -89,3 +89,86 @@ def test_bench_train_data_mode():
     assert d["metric"] == "train_data_rows_per_sec" and d["value"] > 0
     assert d["build_pos_average"]["rows_out"] < d["build_raw"]["rows_out"] == 50000
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
+
+
+# ---- world_size 2 through the real engine: two processes share the one GPU of the box, the packed rows are
+# exchanged with a host-staged gloo all-gather (RCCL cannot put two ranks on one device)
+_CHILD2 = r"""
+import os, sys, pickle
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+from dotsboxesaz_amd import nn as dnn
+from dotsboxesaz_amd import self_play as sp
+from dotsboxesaz_amd.coach import Coach
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+
+
+class FormulaNN:
+    kind = "formula"
+    shape = {}
+    def __init__(self, params): pass
+    def load_parameters(self, g, to_device=None): pass
+
+
+params = dnn.resnet_params(3, 3, 16, 1)
+params["self_play"] = {"num_games": 11, "reuse_mcts_tree": True, "noise": [0.8, 0.25],
+                       "mcts": {"mcts_num_read": 30, "mcts_cpuct": [1.25, 19652], "temperature": {0: 1.0, 6: 0.02}}}
+df = sp.generate_games(None, 2, FormulaNN, 11, params, rows=3, cols=3, n_slots=4, dist=dist)
+# Coach.selfplay, same exchange: the replay store of EVERY rank receives all games' rows
+params["nn"]["model_class"] = dnn.ResNetZero
+params["nn"]["train_params"] = {"train_split": 0.9}
+torch.manual_seed(0)
+coach = Coach(params, 3, 3, n_slots=4, dist=dist, nn_precision=0)
+rec = coach.selfplay(0)
+chunk = coach.store.chunks[0]["rows"]
+games = sp.unpack_rows(chunk.cpu().numpy(), 48, 32)["game_idx"]
+coach.close()
+if rank == 0:
+    with open(sys.argv[1], "wb") as f:
+        pickle.dump((df, rec, np.unique(games).tolist(), len(games)), f)
+dist.barrier()
+dist.destroy_process_group()
+print("OK")
+"""
+
+
+def test_generate_games_and_coach_selfplay_world2(tmp_path):
+    """self_play.py:291-306 with two workers: the frame of rank 0 holds every game exactly once and is
+    IDENTICAL to the single-process run (Philox streams are keyed by game index, not by rank)."""
+    import pickle
+    from dotsboxesaz_amd import nn as dnn
+    from dotsboxesaz_amd import self_play as sp
+    out = str(tmp_path / "rank0.pkl")
+    procs = []
+    for rank in range(2):
+        env = _env(29641)
+        env.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, "-c", _CHILD2 % REPO, out], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        o, _ = p.communicate(timeout=900)
+        assert p.returncode == 0 and "OK" in o, o[-3000:]
+    with open(out, "rb") as f:
+        df, rec, coach_games, coach_rows = pickle.load(f)  # written by this test's own child process
+
+    class FormulaNN:
+        kind = "formula"
+        shape = {}
+
+        def __init__(self, params):
+            pass
+
+        def load_parameters(self, g, to_device=None):
+            pass
+
+    params = dnn.resnet_params(3, 3, 16, 1)
+    params["self_play"] = {"num_games": 11, "reuse_mcts_tree": True, "noise": [0.8, 0.25],
+                           "mcts": {"mcts_num_read": 30, "mcts_cpuct": [1.25, 19652], "temperature": {0: 1.0, 6: 0.02}}}
+    single = sp.generate_games(None, 2, FormulaNN, 11, params, rows=3, cols=3, n_slots=4)
+    games = df.index.get_level_values("game_idx")
+    assert sorted(set(games)) == list(range(11)) and not df.index.duplicated().any()
+    assert df.equals(single)
+    assert coach_games == list(range(11)) and rec["rows"] == coach_rows and rec["games"] == 11
