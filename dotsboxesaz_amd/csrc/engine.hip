@@ -167,6 +167,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     if (cfg->match_play && (cfg->evaluator2 < 0 || cfg->evaluator2 >= DBAZ_EVAL_EXTERNAL || cfg->evaluator == DBAZ_EVAL_EXTERNAL))
         return set_error(nullptr, DBAZ_EINVAL, "match play needs two device evaluators");
     if (cfg->n_temp < 0 || cfg->n_temp > 8) return set_error(nullptr, DBAZ_EINVAL, "n_temp must be in 0..8");
+    if (cfg->transposition_cache < 0 || cfg->transposition_cache > 2) return set_error(nullptr, DBAZ_EINVAL, "transposition_cache must be 0, 1 or 2");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -244,7 +245,12 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     {
         auto nn_ev = [](int ev) { return ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN; };
         // off in two-model match play, like the reference (self_play.py:230): a kept twin may belong to the other model
-        if (cfg->transposition_cache == 0 && !cfg->match_play && nn_ev(cfg->evaluator)) {
+        // transposition_cache = 2 forces the table on for the formula evaluators too (their (p, v) is a pure function
+        // of the same key): the hit path -- twin's prior row, v from its meta block, re-insertion at re-root -- then runs
+        // under the oracle-pinned searches of the test-suite
+        const bool formula_ev = cfg->evaluator == DBAZ_EVAL_FORMULA_HASH || cfg->evaluator == DBAZ_EVAL_FORMULA_UNIFORM;
+        if (!cfg->match_play && ((cfg->transposition_cache == 0 && nn_ev(cfg->evaluator)) ||
+                                 (cfg->transposition_cache == 2 && (nn_ev(cfg->evaluator) || formula_ev)))) {
             size_t tcap = 64;
             while (tcap < 2 * (size_t)g.cap) tcap <<= 1; // <= 50 % load even when every node of the pool is a distinct position
             CREATE_CHECK(dmalloc(e, &B.tt, ns * tcap));

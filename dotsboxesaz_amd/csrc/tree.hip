@@ -628,7 +628,9 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
         const int ev = model ? cfg.evaluator2 : cfg.evaluator;
         if (ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN) need_eval = model;
         int hit = -1;
-        if (need_eval >= 0 && B.tt) {
+        // (the table exists for network evaluators, and for the formula evaluators when forced on -- transposition_cache
+        // = 2 -- so that the hit path can be compared with the oracle bit for bit)
+        if (B.tt && ev != DBAZ_EVAL_EXTERNAL) {
             // lanes 0..TT_PROBES-1 read the probe window; a candidate is verified against the live tree
             const uint64_t h = formula_hash(m.st);
             const unsigned long long *tt = B.tt + (size_t)slot * ((size_t)B.tt_mask + 1);
@@ -716,7 +718,7 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
         float *Prow = reinterpret_cast<float *>(nd + META_DW);
         const int ev = (cfg.match_play && S->model) ? cfg.evaluator2 : cfg.evaluator;
         const bool formula = ev == DBAZ_EVAL_FORMULA_HASH || ev == DBAZ_EVAL_FORMULA_UNIFORM;
-        if (B.tt && !formula) hit = S->leaf_hit;
+        if (B.tt) hit = S->leaf_hit;
         if (hit >= 0) {
             // transposition: the twin's row is masked(p) / sum for the same valid moves, its v the same network output
             const uint32_t *tw = node_ptr(pool, g, hit);
@@ -738,7 +740,7 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
                 Prow[i] = renorm ? ldsf[i] / s : ldsf[i];
             v = formula ? formula_v(h, ev) : B.evalV[slot];
         }
-        if (B.tt && !formula && lane == 0) {
+        if (B.tt && lane == 0) {
             nd[12] = __float_as_uint(v); // a later twin reads the value here
             if (hit < 0) {
                 // insert: first empty / stale-epoch / same-tag entry of the probe window, else a hash-chosen victim
@@ -1051,7 +1053,7 @@ __global__ void __launch_bounds__(WAVE) k_set_positions(Geo g, SearchCfg cfg, Tr
     if (lane == 0) {
         S->error = err;
         S->phase = err ? PH_ERROR : PH_IDLE;
-        S->n_search = S->sum_path = S->n_eval = S->n_term = 0;
+        S->n_search = S->sum_path = S->n_eval = S->n_term = S->n_hit = 0;
         S->pool_high = 1;
     }
 }
@@ -1165,7 +1167,7 @@ __global__ void __launch_bounds__(WAVE) k_selfplay_start(Geo g, SearchCfg cfg, T
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
     if (lane == 0) {
         S->error = 0;
-        S->n_search = S->sum_path = S->n_eval = S->n_term = 0;
+        S->n_search = S->sum_path = S->n_eval = S->n_term = S->n_hit = 0;
         S->pool_high = 1;
     }
     // deterministic initial assignment: slot i takes game first+i (the dispenser starts behind them)

@@ -53,7 +53,8 @@ class Engine:
         cfg.nn_precision = int(nn_precision)
         cfg.match_play = int(bool(match_play))
         cfg.evaluator2 = self.EVALUATORS[evaluator2] if isinstance(evaluator2, str) else int(evaluator2)
-        cfg.transposition_cache = 0 if transposition_cache else 1
+        # True: on for network evaluators; False: off; "force": on for the formula evaluators too (parity tests)
+        cfg.transposition_cache = 2 if transposition_cache == "force" else (0 if transposition_cache else 1)
         self.cfg = cfg
         self._drained = []
         self.h = C.c_void_p()

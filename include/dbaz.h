@@ -70,8 +70,9 @@ typedef struct {
     int32_t match_play;     /* two-model match play (self_play.compute_elo, :309-344): the evaluator of a move's
                                search is model (root.to_play XOR game_idx&1) */
     int32_t evaluator2;     /* DBAZ_EVAL_* of model 1 (match play) */
-    int32_t transposition_cache; /* 0 = on for network evaluators (default), 1 = off.  The reference caches (p, v) by
-                             * position hash (utils/proxies.py:35-43); results are identical either way */
+    int32_t transposition_cache; /* 0 = on for network evaluators (default), 1 = off, 2 = on for network AND formula
+                             * evaluators (parity tests of the hit path).  The reference caches (p, v) by position hash
+                             * (utils/proxies.py:35-43); results are identical either way */
     int32_t reserved0;
 } dbaz_config;
 

@@ -16,10 +16,10 @@ CASES = [str(c) for c in _G["cases"]]
 class HipTree:
     """Two identical slots (slot independence) driven like mcts.UCT_search / init_mcts_tree."""
 
-    def __init__(self, rows, cols, start, kind, cap=0):
+    def __init__(self, rows, cols, start, kind, cap=0, tt=True):
         from dotsboxesaz_amd.engine import Engine
         self.e = Engine(rows, cols, 2, mcts_num_read=800, evaluator="uniform" if kind == 1 else "formula",
-                        nodes_per_slot=cap)
+                        nodes_per_slot=cap, transposition_cache=tt)
         self.e.set_positions([list(start), list(start)])
 
     def search(self, n, cpuct, dirichlet, noise):
@@ -32,11 +32,19 @@ class HipTree:
         self.e.advance(move, reuse)
 
 
+# B1 (utils/proxies.py:35-43): tt="force" switches the per-game transposition table on for the formula evaluators
+# (dbaz_config.transposition_cache = 2), so that every oracle-pinned search below also runs through the table's
+# hit path (twin's prior row + v from its meta block; re-insertion at re-root) -- bit-exact like the plain run.
+TT_MODES = [True, "force"]
+_HITS = {}
+
+
+@pytest.mark.parametrize("tt", TT_MODES)
 @pytest.mark.parametrize("name", CASES)
-def test_golden_case(name):
+def test_golden_case(name, tt):
     g = _G
     rows, cols, kind, c0, c1 = g[name + "_cfg"]
-    t = HipTree(int(rows), int(cols), g[name + "_start"], int(kind))
+    t = HipTree(int(rows), int(cols), g[name + "_start"], int(kind), tt=tt)
     for si, (op, a, b, c) in enumerate(g[name + "_script"]):
         key = "%s_s%d_" % (name, si)
         if op == 0:
@@ -53,19 +61,35 @@ def test_golden_case(name):
                 assert r["root_tv"][s].view(np.uint32) == g[key + "root_tv"].view(np.uint32)
         else:
             t.advance(int(a), bool(b))
+    if tt == "force":
+        _HITS[name] = t.e.counters()["cache_hits"]
+    else:
+        assert t.e.counters()["cache_hits"] == 0  # formula evaluators: table off unless forced
     t.e.close()
+
+
+def test_forced_table_was_hit_in_the_golden_scripts():
+    if not _HITS:
+        pytest.skip("the force-mode golden cases did not run in this session")
+    assert sum(_HITS.values()) > 0 and sum(1 for v in _HITS.values() if v > 0) >= min(5, len(_HITS)), _HITS
 
 
 @pytest.mark.parametrize("rows,cols,n_slots,sims,kind", [(3, 3, 512, 120, 0), (6, 6, 384, 200, 0), (6, 6, 64, 300, 1),
                                                          (9, 9, 96, 150, 0), (2, 4, 128, 90, 0)])
-def test_many_slots_vs_oracle(rows, cols, n_slots, sims, kind):
+@pytest.mark.parametrize("tt", TT_MODES)
+def test_many_slots_vs_oracle(rows, cols, n_slots, sims, kind, tt):
     """Every slot searches a different position; three searches with tree reuse, noise on the
     second one; root arrays compared with the C oracle slot by slot."""
-    _run_vs_oracle(rows, cols, n_slots, sims, kind, (1.25, 19652), True, n_slots + sims)
+    hits = _run_vs_oracle(rows, cols, n_slots, sims, kind, (1.25, 19652), True, n_slots + sims, tt)
+    if tt != "force":
+        assert hits == 0
+    elif rows * cols < 81:  # (150 reads on a 9x9 board rarely transpose: 200 actions, shallow trees)
+        assert hits > 0
 
 
+@pytest.mark.parametrize("tt", TT_MODES)
 @pytest.mark.parametrize("seed", range(14))
-def test_random_configuration_sweep(seed):
+def test_random_configuration_sweep(seed, tt):
     """Seeded sweep over board shapes (1x1 .. 9x9, non-square included), slot counts, read counts,
     cpuct constants, evaluator formula and fresh-vs-reused trees."""
     rng = np.random.RandomState(1000 + seed)
@@ -77,10 +101,11 @@ def test_random_configuration_sweep(seed):
     n_slots = int(rng.randint(3, 40))
     sims = int(rng.randint(4, 140))
     cpuct = (float(rng.choice([0.5, 1.25, 2.0, 4.0])), float(rng.choice([100.0, 19652.0])))
-    _run_vs_oracle(rows, cols, n_slots, sims, int(rng.randint(0, 2)), cpuct, bool(rng.randint(0, 2)), seed)
+    hits = _run_vs_oracle(rows, cols, n_slots, sims, int(rng.randint(0, 2)), cpuct, bool(rng.randint(0, 2)), seed, tt)
+    assert tt == "force" or hits == 0
 
 
-def _run_vs_oracle(rows, cols, n_slots, sims, kind, cpuct, reuse, seed):
+def _run_vs_oracle(rows, cols, n_slots, sims, kind, cpuct, reuse, seed, tt=True):
     from dotsboxesaz_amd.engine import Engine
     d = O.dims(rows, cols)
     rng = np.random.RandomState(seed)
@@ -98,7 +123,7 @@ def _run_vs_oracle(rows, cols, n_slots, sims, kind, cpuct, reuse, seed):
             st = tmp
             mv.append(m)
         starts.append(mv)
-    e = Engine(rows, cols, n_slots, mcts_num_read=sims, evaluator="uniform" if kind else "formula")
+    e = Engine(rows, cols, n_slots, mcts_num_read=sims, evaluator="uniform" if kind else "formula", transposition_cache=tt)
     e.set_positions(starts)
     trees = [O.Tree(d, O.state_from_moves(d, mv)) for mv in starts]
     ev = O.Evaluator(kind)
@@ -133,7 +158,9 @@ def _run_vs_oracle(rows, cols, n_slots, sims, kind, cpuct, reuse, seed):
             else:
                 trees[s].advance(int(moves[s]), reuse)
         e.advance(moves, reuse)
+    hits = e.counters()["cache_hits"]
     e.close()
+    return hits
 
 
 def test_illegal_advance_raises_value_error():

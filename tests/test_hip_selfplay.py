@@ -27,9 +27,12 @@ def compare_rows(got, rows_slice, g, name):
     assert np.array_equal(got["game_idx"], g[name + "_index"][r, 1])
 
 
+# tt="force": the per-game transposition table (B1, utils/proxies.py:35-43) switched on for the formula evaluators, so
+# the reference's golden games and the oracle replays also pin its hit path (see test_hip_mcts.TT_MODES)
+@pytest.mark.parametrize("tt", [True, "force"])
 @pytest.mark.parametrize("name", FORMULA_CASES)
 @pytest.mark.parametrize("n_slots", [1, 4])
-def test_golden_games_teacher_forced(name, n_slots):
+def test_golden_games_teacher_forced(name, n_slots, tt):
     """The reference's sampled moves and Dirichlet vectors are injected; every row of
     get_datasets must match bit for bit (n_slots=1 plays the games one after the other in
     one slot, n_slots=4 concurrently)."""
@@ -38,7 +41,7 @@ def test_golden_games_teacher_forced(name, n_slots):
     rows, cols, sims, a, c, reuse, n_games, _seed = g[name + "_cfg"]
     temp = {int(k): float(v) for k, v in g[name + "_temp"]}
     e = Engine(int(rows), int(cols), n_slots, mcts_num_read=int(sims), noise=(a, c), temperature=temp,
-               reuse_tree=bool(reuse), evaluator="uniform" if name == "sp33_uniform" else "formula")
+               reuse_tree=bool(reuse), evaluator="uniform" if name == "sp33_uniform" else "formula", transposition_cache=tt)
     games = golden_games(g, name)
     for gi, gg in enumerate(games):
         e.selfplay_script(gi, gg["moves"], gg["noise"])
@@ -46,6 +49,7 @@ def test_golden_games_teacher_forced(name, n_slots):
     e.run()
     cnt = e.counters()
     assert cnt["games_finished"] == len(games) and cnt["error_slots"] == 0
+    assert (cnt["cache_hits"] > 0) == (tt == "force")  # whole games with tree reuse: transpositions always occur
     got = e.fetch_samples()
     all_rows = np.concatenate([gg["rows"] for gg in games])
     assert np.array_equal(got["played"], np.concatenate([gg["moves"] for gg in games]))
@@ -53,19 +57,21 @@ def test_golden_games_teacher_forced(name, n_slots):
     e.close()
 
 
+@pytest.mark.parametrize("tt", [True, "force"])
 @pytest.mark.parametrize("rows,cols,n_slots,n_games,sims,reuse", [(3, 3, 64, 200, 40, True), (3, 3, 32, 70, 30, False),
                                                                   (6, 6, 48, 48, 60, True), (2, 3, 16, 40, 50, True)])
-def test_device_sampled_games_vs_oracle(rows, cols, n_slots, n_games, sims, reuse):
+def test_device_sampled_games_vs_oracle(rows, cols, n_slots, n_games, sims, reuse, tt):
     """Production path: moves sampled on the device (Philox), slots refilled as games end.
     The oracle replays each game teacher-forced with the device's moves; all rows must be
     bit-identical (noise off: numpy's Dirichlet stream cannot be matched on the device)."""
     from dotsboxesaz_amd.engine import Engine
     e = Engine(rows, cols, n_slots, mcts_num_read=sims, noise=(0.0, 0.0), reuse_tree=reuse, evaluator="formula",
-               seed=1234)
+               seed=1234, transposition_cache=tt)
     e.selfplay_start(n_games, 100)
     e.run()
     cnt = e.counters()
     assert cnt["games_finished"] == n_games and cnt["active_slots"] == 0 and cnt["error_slots"] == 0
+    assert (cnt["cache_hits"] > 0) == (tt == "force")
     got = e.fetch_samples()
     assert sorted(set(got["game_idx"])) == list(range(100, 100 + n_games))
     d = O.dims(rows, cols)
