@@ -30,19 +30,32 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, de
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16
 
 
-def cpu_baseline(rows, cols, sims, budget_s, channels, blocks):
-    """Oracle (C tree/rules restatement + torch fp32 CPU network, batch 1) timed on the host
-    cores: the reference's CPU path, bounded sample."""
+def host_cores():
+    """Cores this process may use: the affinity mask, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _cpu_worker(job):
+    """One self-play game loop of the oracle on ONE core (torch intra-op threads = 1): C tree / rules
+    restatement + torch fp32 CPU ResNetZero at batch 1 with the reference's (p, v) cache by position.
+    Returns (expansions, seconds)."""
+    rows, cols, sims, budget_s, channels, blocks, seed = job
     import torch
+    torch.set_num_threads(1)
     from oracle import oracle as O
     from oracle import nn_ref
     torch.manual_seed(0)
-    torch.set_num_threads(min(8, os.cpu_count() or 1))  # batch-1 convs do not scale past a few cores
     model = nn_ref.ResNetZeroRef(rows, cols, channels, blocks)
     model.train(False)
     d = O.dims(rows, cols)
-
-    cache = {}  # the reference's (p, v) cache by position hash (utils/proxies.py:35-43)
+    cache = {}  # utils/proxies.py:35-43
 
     def fn(dd, s):
         f = O.features(dd, s)
@@ -55,36 +68,52 @@ def cpu_baseline(rows, cols, sims, budget_s, channels, blocks):
 
     ev = O.Evaluator(fn)
     tree = O.Tree(d, O.new_state(d))
-    rng = np.random.RandomState(0)
+    rng = np.random.RandomState(seed)
     t0 = time.perf_counter()
     n0 = 0
-    done = 0
     while time.perf_counter() - t0 < budget_s:
         noise = rng.dirichlet(np.full(d.A, 0.8))
         left = sims
+        vis = None
         while left > 0 and time.perf_counter() - t0 < budget_s:
             k = min(40, left)
             vis = tree.search(k, ev, dirichlet=(0.8, 0.25) if left == sims else (0.0, 0.0), noise=noise)
             left -= k
-        done = tree.counters()[0]
         if left == 0:
+            # temperature 1 for the first moves like the reference's schedule; argmax afterwards
             tree.advance(int(np.argmax(vis)), True)
             if tree.is_terminal:
-                n0 += done
+                n0 += tree.counters()[0]
                 tree = O.Tree(d, O.new_state(d))
-    dt = time.perf_counter() - t0
-    total = n0 + tree.counters()[0]
-    return dict(value=total / dt, unit="expansions/s", cores=int(torch.get_num_threads()), kind="port",
-                sample="%dx%d, 1 game, %d sims/move, sequential search, torch fp32 CPU ResNetZero %dx%d batch 1 with the "
-                       "reference's (p, v) cache by position, %.0f s (%d expansions)" % (rows, cols, sims, blocks, channels, dt, total))
+    return n0 + tree.counters()[0], time.perf_counter() - t0
 
 
-def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, torch):
-    """One timed region on this rank's GPU; returns the raw measurements."""
+def cpu_baseline(rows, cols, sims, budget_s, channels, blocks, max_procs=64):
+    """The reference's CPU path as the oracle restates it, one process per host core (the reference
+    runs mp.cpu_count()-1 worker processes, self_play.py:292), bounded sample: every process plays its
+    own game for budget_s seconds.  Must run BEFORE this process touches the GPU (it forks workers)."""
+    import multiprocessing as mp
+    cores = host_cores()
+    procs = min(cores, max_procs)
+    jobs = [(rows, cols, sims, budget_s, channels, blocks, i) for i in range(procs)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(procs) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
+    rate = sum(r[0] / r[1] for r in res)
+    return dict(value=rate, unit="expansions/s", cores=procs, host_cores=cores, kind="port", per_core=rate / procs,
+                sample="%dx%d, %d sims/move, %d processes x 1 thread (one per host core), each its own game: sequential search "
+                       "(C oracle) + torch fp32 CPU ResNetZero %dx%d at batch 1 with the reference's (p, v) cache by position, "
+                       "%.0f s each (%d expansions in all, %.0f s wall incl. process start)"
+                       % (rows, cols, sims, procs, blocks, channels, budget_s, total, wall))
+
+
+def make_engine(args, precision, rank, local_rank, torch, slots=None):
     from dotsboxesaz_amd.engine import Engine
     from dotsboxesaz_amd import nn as dnn
     rows = cols = args.board
-    eng = Engine(rows, cols, args.slots, mcts_num_read=args.sims, noise=(0.8, 0.25), reuse_tree=True,
+    eng = Engine(rows, cols, slots or args.slots, mcts_num_read=args.sims, noise=(0.8, 0.25), reuse_tree=True,
                  evaluator=args.evaluator, seed=1000 + rank, device=local_rank, nn_precision=precision,
                  nodes_per_slot=args.nodes_per_slot)
     if args.evaluator == "resnet":
@@ -94,10 +123,27 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
     elif args.evaluator == "simplenn":
         torch.manual_seed(0)
         eng.load_state_dict(dnn.SimpleNN().state_dict(), "simplenn")
-    # synthetic mid-game population: slot i starts (i*37 mod 0.7E) random legal plies into a game
+    return eng
+
+
+def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, torch):
+    """One timed region on this rank's GPU; returns the raw measurements.
+
+    Population (synthetic input, built before the W warm-up steps): slot i starts (i*37 mod 0.7E) uniformly random
+    legal plies into a game, and its FIRST search is cut to (i*61 mod sims)+1 reads; the engine then runs sims+64
+    untimed preparation steps, after which every slot is in its second or later search of a game -- a re-rooted tree
+    with the reused subtree, read counters spread uniformly over [0, sims) -- i.e. the steady state of a long
+    self-play run, which the K timed steps then sample (with fresh trees a 20-step window saw
+    path length 2.9 and no terminal leaves)."""
+    eng = make_engine(args, precision, rank, local_rank, torch)
     span = max(1, int(0.7 * eng.E))
     eng.selfplay_fastforward((np.arange(args.slots) * 37) % span)
+    prep = 0
+    if not args.fresh_population:
+        eng.selfplay_stagger((np.arange(args.slots) * 61) % max(1, args.sims) + 1)
+        prep = args.sims + 64
     eng.selfplay_start(1 << 40, rank * (1 << 32))
+    eng.step(prep)
 
     def sync_all():
         eng.sync()
@@ -120,7 +166,7 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
         raise SystemExit("engine reported %d slots in error (node pool exhausted?)" % c1["error_slots"])
     m = {k: c1[k] - c0[k] for k in ("expansions", "nn_evals", "sum_path", "terminal_leaves", "moves_played", "cache_hits")}
     m.update(dt=dt, ms_total=c1["ms_total"], ms_nn_tower=c1["ms_nn_tower"], pool_high_water=c1["pool_high_water"],
-             nodes_per_slot=eng.cfg.nodes_per_slot or 10 * (args.sims + 2), E=eng.E)
+             nodes_per_slot=eng.cfg.nodes_per_slot or 10 * (args.sims + 2), E=eng.E, prep_steps=prep)
     if dist is not None:
         tdev = torch.tensor([float(m["expansions"]), float(m["nn_evals"]), dt], dtype=torch.float64).cuda()
         mx = tdev.clone()
@@ -132,39 +178,50 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
     return eng, m
 
 
-def full_games(args, rank, local_rank, world, torch):
-    """Direct games/s: args.full_games complete games from the empty board (slots refilled as games
-    end), samples fetched, wall clock around everything after engine construction."""
-    from dotsboxesaz_amd.engine import Engine
-    from dotsboxesaz_amd import nn as dnn
-    rows = cols = args.board
-    eng = Engine(rows, cols, args.slots, mcts_num_read=args.sims, noise=(0.8, 0.25), reuse_tree=True,
-                 evaluator=args.evaluator, seed=1000 + rank, device=local_rank, nn_precision=args.precision)
-    if args.evaluator == "resnet":
-        torch.manual_seed(0)
-        model = dnn.ResNetZero(dnn.resnet_params(rows, cols, args.channels, args.blocks))
-        eng.load_state_dict(model.state_dict(), "resnet", **model.shape)
+def play_complete_games(args, n_games, slots, rank, local_rank, torch, budget_s=0.0):
+    """Direct games/s: n_games complete games from the empty board (slots refilled as games end), samples
+    fetched, wall clock around everything after engine construction.  budget_s > 0 stops a run that takes
+    longer (reported as partial: the rate then covers the games finished so far)."""
+    eng = make_engine(args, args.precision, rank, local_rank, torch, slots=slots)
     eng.sync()
     t0 = time.perf_counter()
-    eng.selfplay_start(args.full_games, 0)
-    eng.run()
-    got = eng.fetch_samples()
+    eng.selfplay_start(n_games, rank * n_games)
+    rows_seen = 0
+    partial = False
+    while True:
+        eng._ck(eng._L.dbaz_run(eng.h, 1024))
+        c = eng.counters()
+        if c["active_slots"] == 0:
+            break
+        if c["blocked_slots"] > 0 or c["rows_ready"] > (1 << 20):
+            rows_seen += len(eng._fetch_once()["z"])
+        if budget_s > 0 and time.perf_counter() - t0 > budget_s:
+            partial = True
+            break
+    rows_seen += len(eng._fetch_once()["z"])
     dt = time.perf_counter() - t0
     c = eng.counters()
-    out = {"metric": "selfplay_games_per_sec", "value": c["games_finished"] / dt, "unit": "games/s", "n_gpus": 1,
-           "higher_is_better": True, "data": "synthetic", "seconds": dt, "games": c["games_finished"],
+    out = {"value": c["games_finished"] / dt, "unit": "games/s", "seconds": dt, "games": c["games_finished"],
+           "games_requested": n_games, "slots": slots, "partial": partial,
            "expansions": c["expansions"], "expansions_per_sec": c["expansions"] / dt,
            "expansions_per_game": c["expansions"] / max(1, c["games_finished"]),
-           "rows": int(len(got["z"])), "rows_per_game": len(got["z"]) / max(1, c["games_finished"]),
+           "rows": rows_seen, "rows_per_game": rows_seen / max(1, c["games_finished"]),
            "mean_path_len": c["sum_path"] / max(1, c["expansions"]),
            "terminal_leaf_fraction": c["terminal_leaves"] / max(1, c["expansions"]),
            "cache_hit_fraction": c["cache_hits"] / max(1, c["expansions"]),
-           "pool_high_water": c["pool_high_water"], "steps": c["steps"],
-           "config": {"workload": "%dx%d board, %d complete games on %d slots, %d sims/move, evaluator=%s %dx%d, precision %d"
-                                  % (rows, cols, args.full_games, args.slots, args.sims, args.evaluator, args.blocks,
-                                     args.channels, args.precision)}}
-    print(json.dumps(out), flush=True)
+           "pool_high_water": c["pool_high_water"], "steps": c["steps"]}
     eng.close()
+    return out
+
+
+def full_games(args, rank, local_rank, world, torch):
+    rows = cols = args.board
+    out = {"metric": "selfplay_games_per_sec", "n_gpus": 1, "higher_is_better": True, "data": "synthetic"}
+    out.update(play_complete_games(args, args.full_games, args.slots, rank, local_rank, torch))
+    out["config"] = {"workload": "%dx%d board, %d complete games on %d slots, %d sims/move, evaluator=%s %dx%d, precision %d"
+                                 % (rows, cols, args.full_games, args.slots, args.sims, args.evaluator, args.blocks,
+                                    args.channels, args.precision)}
+    print(json.dumps(out), flush=True)
 
 
 def train_data_bench(args, local_rank, torch):
@@ -273,6 +330,13 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-side-run", action="store_true")
+    ap.add_argument("--fresh-population", action="store_true",
+                    help="skip the population preparation (staggered first searches + sims+64 untimed steps): every tree "
+                         "starts empty, as in round 1's bench")
+    ap.add_argument("--games-leg", type=int, default=-1,
+                    help="complete games played (per rank) AFTER the timed steps for the directly measured games/s of the "
+                         "metric; -1 = one game per slot (the BASELINE config's game count), 0 = skip")
+    ap.add_argument("--games-leg-budget", type=float, default=240.0, help="wall-clock cap of the games leg in seconds")
     ap.add_argument("--full-games", type=int, default=0,
                     help="instead of timing K steps, play this many COMPLETE games from the empty board and report "
                          "games/s and expansions/game measured directly (one JSON line, metric selfplay_games_per_sec)")
@@ -284,6 +348,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    special = args.full_games > 0 or args.train_data > 0
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not special:
+        # before anything touches the GPU: the baseline forks one worker process per host core
+        cpu = cpu_baseline(args.board, args.board, args.sims, args.cpu_seconds, args.channels, args.blocks)
     import torch
     dist = None
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # launched by torch.distributed.run
@@ -311,6 +380,18 @@ def main():
         eng0, m0 = run_engine(args, 0, st, max(5, args.warmup // 5), rank, local_rank, world, dist, torch)
         eng0.close()
         side = (m0, st)
+    # the second half of the metric, measured directly: complete games from the empty board on every rank's slots
+    leg = None
+    n_leg = args.slots if args.games_leg < 0 else args.games_leg
+    if n_leg > 0:
+        leg = play_complete_games(args, n_leg, args.slots, rank, local_rank, torch, budget_s=args.games_leg_budget)
+        if dist is not None:
+            t = torch.tensor([float(leg["games"]), leg["seconds"]], dtype=torch.float64).cuda()
+            mx = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            leg["games_all_ranks"], leg["seconds_max_over_ranks"] = float(t[0]), float(mx[1])
+            leg["value"] = float(t[0]) / float(mx[1])
 
     if rank == 0:
         rows = cols = args.board
@@ -324,7 +405,7 @@ def main():
                      "f32 via f16x3 (hi,lo)-split MFMA, f32 accumulate; max |dp|,|dv| vs torch fp32 = 1e-6 (tests/test_hip_nn.py)",
             "data": "synthetic",
             "config": {"workload": "%dx%d board, %d concurrent games/GPU, %d sims/move, evaluator=%s %dx%d "
-                                   "random-init, noise (0.8,0.25), tree reuse, mid-game start population"
+                                   "random-init, noise (0.8,0.25), tree reuse, mid-game steady-state population"
                                    % (rows, cols, args.slots, args.sims, args.evaluator, args.blocks, args.channels),
                        "baseline_config": "configs[2]" if (args.board, args.slots, args.sims) == (6, 8192, 800) else "custom",
                        "parallelism": "games sharded, %d rank(s)" % world},
@@ -337,9 +418,15 @@ def main():
         }
         # games/s: expansions/s divided by the measured mean expansions of a full game
         # (DESIGN.md "Measurement"; 6x6 @ 800 sims: 63.2k)
-        exp_per_game = {(6, 800): 63201.0, (3, 100): 1901.0, (9, 1600): 280481.0}.get((args.board, args.sims))
+        out["population"] = ("steady state: staggered first searches + %d untimed preparation steps" % m["prep_steps"]
+                             if m["prep_steps"] else "fresh trees")
+        if leg:
+            out["games_per_sec"] = leg["value"]  # whole-job aggregate, measured on complete games
+            out["games_leg"] = leg
+        exp_per_game = (leg or {}).get("expansions_per_game") or \
+            {(6, 800): 63201.0, (3, 100): 1901.0, (9, 1600): 280481.0}.get((args.board, args.sims))
         if exp_per_game:
-            out["games_per_sec_est"] = out["value"] / exp_per_game
+            out["games_per_sec_est"] = out["value"] / exp_per_game  # step rate / expansions per game: an estimate
             out["expansions_per_game_assumed"] = exp_per_game
         # tree kernels: HBM roofline with SURVEY 8d's algorithmic bytes per simulation at the measured path length
         A = 2 * HW
@@ -378,8 +465,8 @@ def main():
                                      "roofline": tower_roofline(args, m0, st, 0)}
         if gather:
             out["replay_allgather"] = gather
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rows, cols, args.sims, args.cpu_seconds, args.channels, args.blocks)
+        if cpu:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

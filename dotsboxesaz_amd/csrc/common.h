@@ -25,7 +25,8 @@ struct Geo {
 //  dw 9      move (i16) | to_play (u8) << 16 | just_played+1 (u8) << 24
 //  dw 10     b2c2[0] (i16) | b2c2[1] (i16) << 16
 //  dw 11     flags (u8: 1 expanded, 2 terminal) | result+1 (u8) << 8 | deepness (u16) << 16
-//  dw 12..15 reserved
+//  dw 12     network value v of the node's position (written at expansion; a transposition twin reads it)
+//  dw 13..15 reserved
 //  then rows P[AS] f32, W[AS] f32, NS[AS] (visits | same_player << 30), C[AS] i32 child index
 #define META_DW 16
 #define NF_EXPANDED 1u
@@ -67,7 +68,18 @@ struct Slot {
     int32_t tt_epoch;        // 1..255, bumped at every re-root / new game (stale table entries are preferred victims)
     int64_t n_hit;
     int32_t sel_step;        // engine step of the k_select that left the current leaf (k_expand_backup takes only those)
-    int32_t pad0;
+    int32_t ff_reads;        // benchmark population: read budget of the slot's FIRST search (0 = the driver rule)
+    // node pool bookkeeping (re-rooting moves nothing: the dropped part of a tree is collected incrementally)
+    int32_t root;            // node index of the current root
+    int32_t n_free;          // entries on the free stack (recycled node indices)
+    int32_t pend_head, pend_tail; // ring of dropped nodes whose children have not been enumerated yet
+};
+
+// device-side reduction of the Slot array (dbaz_get_counters / dbaz_run poll this instead of copying every Slot)
+struct SlotSummary {
+    unsigned long long n_search, n_eval, n_hit, n_term, sum_path;
+    int32_t active, error, blocked, pool_high;
+    int32_t first_error_slot, first_error_code; // lowest slot index in PH_ERROR (or 0x7fffffff) and its code
 };
 
 struct PathEnt {
@@ -98,6 +110,7 @@ struct SearchCfg {
     uint64_t seed;
     int table_n;             // entries in pbc/sqrt tables
     int step;                // engine step counter of this launch
+    int driver_concurrent;   // this k_select runs next to the driver pass of the same step (self-play stepping)
 };
 
 // device buffer bundle handed to the tree kernels
@@ -114,7 +127,8 @@ struct TreeBufs {
     int32_t *eval_list;// [n_slots] compacted slots needing an NN evaluation (model 0)
     int32_t *eval_list2;// [n_slots] same for model 1 (match play)
     int32_t *n_eval;   // [2] list lengths
-    int32_t *remap;    // [n_slots][cap] compaction scratch
+    int32_t *pend;     // [n_slots][cap] ring: dropped nodes waiting for the collector (their child rows are still needed)
+    int32_t *freel;    // [n_slots][cap] stack: node indices ready for reuse
     int32_t *drv_list;  // [n_slots] slots that need the driver this step (k_driver_scan)
     int32_t *drv_count; // [1]
     unsigned long long *tt; // [n_slots][tt_mask+1] transposition table (tag24 | epoch8 | node index), nullptr = off

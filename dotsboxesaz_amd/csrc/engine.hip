@@ -52,7 +52,8 @@ struct dbaz_engine {
     std::vector<uint8_t> script_has_noise;
     int64_t script_first = -1;
     int n_script = 0;
-    std::vector<int32_t> ff_plies;
+    std::vector<int32_t> ff_plies, ff_reads;
+    SlotSummary *d_sum = nullptr;
     bool selfplay = false;
     bool search_open = false;
     int search_iters_left = 0;
@@ -84,9 +85,11 @@ static int set_error(dbaz_engine *e, int code, const char *fmt, ...)
 
 extern "C" const char *dbaz_last_error(const dbaz_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 extern "C" int dbaz_version(void) { return 1; }
+#ifdef DBAZ_STAMP
+// diagnostic builds (tools/stamp_build_run.sh) only: the shipped library does not export it, include/dbaz.h does not declare it
 int nn_read_stamps(NNState *nn, unsigned long long *out, int n_wg);
-// diagnostic builds (-DDBAZ_STAMP) only; not part of include/dbaz.h
 extern "C" int dbaz_debug_read_stamps(dbaz_engine *e, unsigned long long *out, int n_wg);
+#endif
 
 template <typename T>
 static int dmalloc(dbaz_engine *e, T **p, size_t count, bool zero = true)
@@ -237,7 +240,8 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     CREATE_CHECK(dmalloc(e, &B.eval_list, ns));
     CREATE_CHECK(dmalloc(e, &B.eval_list2, ns));
     CREATE_CHECK(dmalloc(e, &B.n_eval, 4));
-    CREATE_CHECK(dmalloc(e, &B.remap, ns * g.cap, false));
+    CREATE_CHECK(dmalloc(e, &B.pend, ns * g.cap, false));
+    CREATE_CHECK(dmalloc(e, &B.freel, ns * g.cap, false));
     CREATE_CHECK(dmalloc(e, &B.drv_list, ns));
     CREATE_CHECK(dmalloc(e, &B.drv_count, 4));
     B.tt = nullptr;
@@ -268,6 +272,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     CREATE_CHECK(dmalloc(e, &B.games_finished, 2));
     CREATE_CHECK(dmalloc(e, &B.moves_played, 2));
     CREATE_CHECK(dmalloc(e, &e->d_small, 16));
+    CREATE_CHECK(dmalloc(e, &e->d_sum, 1));
     // log / sqrt tables evaluated with the HOST libm (what python's math.log/math.sqrt call),
     // mcts.py:92-94
     {
@@ -482,20 +487,36 @@ extern "C" int dbaz_nn_predict(dbaz_engine *e, int32_t n, const float *X, float 
 }
 
 // ---------------------------------------------------------------- search (M1-M9)
+// Slot array reduced on the device (64 bytes cross PCIe instead of n_slots * sizeof(Slot))
+static int device_summary(dbaz_engine *e, SlotSummary *out)
+{
+    SlotSummary init;
+    memset(&init, 0, sizeof(init));
+    init.first_error_slot = 0x7fffffff;
+    HIP_CHECK_RET(e, hipMemcpyAsync(e->d_sum, &init, sizeof(init), hipMemcpyHostToDevice, e->stream));
+    tree_launch_slot_summary(e->stream, e->B, e->n_slots, e->d_sum);
+    HIP_CHECK_RET(e, hipGetLastError());
+    HIP_CHECK_RET(e, hipMemcpyAsync(out, e->d_sum, sizeof(*out), hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
+    return DBAZ_OK;
+}
+
+static int report_slot_error(dbaz_engine *e, const SlotSummary &s)
+{
+    if (s.error == 0) return DBAZ_OK;
+    const int i = s.first_error_slot;
+    if (s.first_error_code == DBAZ_EPOOL)
+        return set_error(e, DBAZ_EPOOL, "slot %d: node pool exhausted (%d nodes); raise nodes_per_slot", i, e->g.cap);
+    if (s.first_error_code == DBAZ_EILLEGAL) return set_error(e, DBAZ_EILLEGAL, "Illegal move (slot %d)", i);
+    return set_error(e, DBAZ_ESTATE, "slot %d stopped with error %d", i, s.first_error_code);
+}
+
 static int check_slot_errors(dbaz_engine *e)
 {
-    std::vector<Slot> hs(e->n_slots);
-    HIP_CHECK_RET(e, hipMemcpy(hs.data(), e->B.slots, sizeof(Slot) * e->n_slots, hipMemcpyDeviceToHost));
-    for (int i = 0; i < e->n_slots; i++) {
-        if (hs[i].phase == PH_ERROR) {
-            if (hs[i].error == DBAZ_EPOOL)
-                return set_error(e, DBAZ_EPOOL, "slot %d: node pool exhausted (%d nodes); raise nodes_per_slot", i, e->g.cap);
-            if (hs[i].error == DBAZ_EILLEGAL)
-                return set_error(e, DBAZ_EILLEGAL, "Illegal move (slot %d)", i);
-            return set_error(e, DBAZ_ESTATE, "slot %d stopped with error %d", i, hs[i].error);
-        }
-    }
-    return DBAZ_OK;
+    SlotSummary s;
+    int r = device_summary(e, &s);
+    if (r) return r;
+    return report_slot_error(e, s);
 }
 
 extern "C" int dbaz_set_positions(dbaz_engine *e, const int16_t *moves, const int32_t *offsets)
@@ -541,19 +562,22 @@ static int sim_step(dbaz_engine *e, bool with_driver)
     auto is_nn = [](int ev) { return ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN; };
     const bool use_nn = is_nn(e->sc.evaluator);
     const bool use_nn2 = e->sc.match_play && is_nn(e->sc.evaluator2);
-    if (use_nn || use_nn2) HIP_CHECK_RET(e, hipMemsetAsync(e->B.n_eval, 0, 8, s));
     e->sc.step = (int)(e->steps & 0x3FFFFFFF) + 1; // never 0 (a fresh Slot's stamp)
-    tree_launch_select(s, e->g, e->sc, e->B, e->n_slots);
+    e->sc.driver_concurrent = with_driver ? 1 : 0;
     if (with_driver) {
-        // The driver step (move choice, re-rooting with subtree compaction, game turnover) only touches slots whose
-        // reads are done (PH_READY / PH_EMIT); the rest of this step only touches slots that are searching.  A slot's
-        // compaction is one wave working for up to a millisecond, so it runs on a second stream NEXT TO the network
-        // instead of holding up every game; the streams join before the next select.
+        // The driver pass (move choice, O(1) re-root, row emission, game turnover, next search's root preparation) only
+        // touches slots whose reads are done (PH_READY / PH_EMIT); k_select only touches slots that are searching and
+        // skips the ones this very pass starts (stamp).  So the pass runs on a second stream NEXT TO k_select -- both are
+        // short, latency-bound kernels that leave most of the chip idle -- and is joined before the network, which
+        // needs every CU (a resident driver workgroup keeps a k_tower workgroup off its CU).
         HIP_CHECK_RET(e, hipEventRecord(e->ev_fork, s));
         HIP_CHECK_RET(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
         tree_launch_advance_auto(e->stream2, e->g, e->sc, e->B, e->n_slots);
         HIP_CHECK_RET(e, hipEventRecord(e->ev_join, e->stream2));
     }
+    if (use_nn || use_nn2) HIP_CHECK_RET(e, hipMemsetAsync(e->B.n_eval, 0, 8, s));
+    tree_launch_select(s, e->g, e->sc, e->B, e->n_slots);
+    if (with_driver) HIP_CHECK_RET(e, hipStreamWaitEvent(s, e->ev_join, 0));
     if (use_nn) {
         hipEvent_t a = nullptr, b = nullptr;
         if (e->timing) { a = next_event(e); b = next_event(e); }
@@ -565,7 +589,6 @@ static int sim_step(dbaz_engine *e, bool with_driver)
         e->nn_launches++;
     }
     tree_launch_expand_backup(s, e->g, e->sc, e->B, e->n_slots);
-    if (with_driver) HIP_CHECK_RET(e, hipStreamWaitEvent(s, e->ev_join, 0));
     e->steps++;
     HIP_CHECK_RET(e, hipGetLastError());
     return DBAZ_OK;
@@ -614,6 +637,7 @@ extern "C" int dbaz_search_begin(dbaz_engine *e, const int32_t *num_reads, const
     const int32_t *d_reads;
     int r = upload_search_inputs(e, num_reads, noise, &d_reads);
     if (r) return r;
+    e->sc.step = 0;
     tree_launch_search_begin(e->stream, e->g, e->sc, e->B, e->n_slots, d_reads);
     HIP_CHECK_RET(e, hipGetLastError());
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
@@ -663,6 +687,7 @@ extern "C" int dbaz_select(dbaz_engine *e, int32_t *n_active, int16_t *leaf_x, u
     uint8_t *d_ne = cv.take<uint8_t>(ns);
     int32_t *d_na = cv.take<int32_t>(4);
     e->sc.step = (e->sc.step & 0x3FFFFFFF) + 1;
+    e->sc.driver_concurrent = 0;
     tree_launch_select(e->stream, g, e->sc, e->B, e->n_slots);
     HIP_CHECK_RET(e, hipMemsetAsync(d_na, 0, 16, e->stream));
     tree_launch_get_leaves(e->stream, g, e->B, e->n_slots, d_x, d_ne, d_na);
@@ -807,6 +832,15 @@ extern "C" int dbaz_selfplay_fastforward(dbaz_engine *e, const int32_t *plies)
     return DBAZ_OK;
 }
 
+extern "C" int dbaz_selfplay_stagger(dbaz_engine *e, const int32_t *first_reads)
+{
+    if (!e || !first_reads) return e ? set_error(e, DBAZ_EINVAL, "null argument") : DBAZ_EINVAL;
+    for (int i = 0; i < e->n_slots; i++)
+        if (first_reads[i] < 0) return set_error(e, DBAZ_EINVAL, "first_reads[%d] < 0", i);
+    e->ff_reads.assign(first_reads, first_reads + e->n_slots);
+    return DBAZ_OK;
+}
+
 extern "C" int dbaz_selfplay_start(dbaz_engine *e, int64_t n_games, int64_t first_game_idx)
 {
     if (!e || n_games < 0) return e ? set_error(e, DBAZ_EINVAL, "bad argument") : DBAZ_EINVAL;
@@ -847,10 +881,15 @@ extern "C" int dbaz_selfplay_start(dbaz_engine *e, int64_t n_games, int64_t firs
     {
         std::vector<Slot> hs(e->n_slots);
         HIP_CHECK_RET(e, hipMemcpy(hs.data(), B.slots, sizeof(Slot) * e->n_slots, hipMemcpyDeviceToHost));
-        for (int i = 0; i < e->n_slots; i++) hs[i].ff_plies = e->ff_plies.empty() ? 0 : e->ff_plies[i];
+        for (int i = 0; i < e->n_slots; i++) {
+            hs[i].ff_plies = e->ff_plies.empty() ? 0 : e->ff_plies[i];
+            hs[i].ff_reads = e->ff_reads.empty() ? 0 : e->ff_reads[i];
+        }
+        e->ff_reads.clear();
         HIP_CHECK_RET(e, hipMemcpy(B.slots, hs.data(), sizeof(Slot) * e->n_slots, hipMemcpyHostToDevice));
         e->ff_plies.clear();
     }
+    e->sc.step = 0; // searches started here carry stamp 0, which no step ever has
     tree_launch_selfplay_start(s, e->g, e->sc, B, e->n_slots);
     HIP_CHECK_RET(e, hipGetLastError());
     HIP_CHECK_RET(e, hipStreamSynchronize(s));
@@ -872,24 +911,21 @@ extern "C" int dbaz_step(dbaz_engine *e, int32_t k)
     return DBAZ_OK;
 }
 
-static int slot_summary(dbaz_engine *e, dbaz_counters *c)
+static int slot_summary(dbaz_engine *e, dbaz_counters *c, SlotSummary *raw = nullptr)
 {
-    std::vector<Slot> hs(e->n_slots);
-    HIP_CHECK_RET(e, hipMemcpy(hs.data(), e->B.slots, sizeof(Slot) * e->n_slots, hipMemcpyDeviceToHost));
-    c->expansions = c->nn_evals = c->terminal_leaves = c->sum_path = c->cache_hits = 0;
-    c->active_slots = c->error_slots = c->blocked_slots = 0;
-    c->pool_high_water = 0;
-    for (const Slot &s : hs) {
-        c->expansions += s.n_search;
-        c->nn_evals += s.n_eval;
-        c->cache_hits += s.n_hit;
-        c->terminal_leaves += s.n_term;
-        c->sum_path += s.sum_path;
-        if (s.phase == PH_ERROR) c->error_slots++;
-        else if (s.game_idx >= 0 && s.phase != PH_IDLE) c->active_slots++;
-        if (s.phase == PH_EMIT) c->blocked_slots++;
-        c->pool_high_water = std::max<int64_t>(c->pool_high_water, s.pool_high);
-    }
+    SlotSummary s;
+    int r = device_summary(e, &s);
+    if (r) return r;
+    c->expansions = (int64_t)s.n_search;
+    c->nn_evals = (int64_t)s.n_eval;
+    c->cache_hits = (int64_t)s.n_hit;
+    c->terminal_leaves = (int64_t)s.n_term;
+    c->sum_path = (int64_t)s.sum_path;
+    c->active_slots = s.active;
+    c->error_slots = s.error;
+    c->blocked_slots = s.blocked;
+    c->pool_high_water = s.pool_high;
+    if (raw) *raw = s;
     return DBAZ_OK;
 }
 
@@ -1040,12 +1076,14 @@ extern "C" int dbaz_fetch_samples(dbaz_engine *e, int32_t max_rows, int32_t *n_r
     return DBAZ_OK;
 }
 
+#ifdef DBAZ_STAMP
 extern "C" int dbaz_debug_read_stamps(dbaz_engine *e, unsigned long long *out, int n_wg)
 {
     if (!e) return DBAZ_EINVAL;
     (void)hipStreamSynchronize(e->stream);
     return nn_read_stamps(e->nn, out, n_wg) == 0 ? DBAZ_OK : DBAZ_ESTATE;
 }
+#endif
 
 extern "C" int dbaz_replay_rows_dev(dbaz_engine *e, void **rows_dev, int32_t *n_rows, int32_t *row_bytes)
 {

@@ -100,6 +100,116 @@ __device__ void init_node(uint32_t *pool, const Geo &g, int idx, const GState &s
 }
 
 // ------------------------------------------------------------------------------------
+// Node pool of one game.  Re-rooting (init_mcts_tree, mcts.py:163-180) moves nothing: the chosen child
+// simply becomes the root, and the old root -- its link to the kept child cut -- is handed to a
+// collector that enumerates the dropped part of the tree a few nodes per simulation (ring `pend`:
+// dropped nodes whose child row is still needed; stack `freel`: indices ready for reuse).  In steady state
+// one node is created per simulation and GC_PER_STEP are recycled, so the pool never grows past
+// the tree plus one move's worth of garbage.  (Round 1 compacted the kept subtree in place: 2.5-4 MB
+// moved by one wave for 0.4-2 ms per move, on a CU the network's workgroups then could not use.)
+// ------------------------------------------------------------------------------------
+#define GC_PER_STEP 2
+struct PoolState { int n_nodes, n_free, head, tail; };
+
+__device__ __forceinline__ PoolState pool_load(const Slot *S)
+{
+    PoolState q;
+    q.n_nodes = S->n_nodes; q.n_free = S->n_free; q.head = S->pend_head; q.tail = S->pend_tail;
+    return q;
+}
+__device__ __forceinline__ void pool_store(const PoolState &q, Slot *S)
+{
+    S->n_nodes = q.n_nodes; S->n_free = q.n_free; S->pend_head = q.head; S->pend_tail = q.tail;
+}
+__device__ __forceinline__ int ring_at(int i, int cap) { return i >= cap ? i - cap : i; }
+
+// Takes up to NB (<= 4) nodes off the pending ring: their children join the ring, the nodes themselves the free
+// stack.  Wave-cooperative, wave-uniform state.  Two halves so that the row loads of the batch (all in flight
+// together) can overlap other work of the wave: gc_issue reserves the entries and requests their child rows,
+// gc_finish consumes them.  Only entries that were on the ring at gc_issue are read.
+template <int NB>
+struct GcBatch {
+    int k;
+    int node[NB];
+    int32_t c[NB][4];
+};
+
+template <int NB>
+__device__ __forceinline__ void gc_issue(GcBatch<NB> &b, const Geo &g, const TreeBufs &B, int slot, uint32_t *pool, PoolState &q, int lane)
+{
+    const int avail = q.tail - q.head;
+    b.k = avail < NB ? (avail > 0 ? avail : 0) : NB;
+    if (b.k == 0) return;
+    const int32_t *pend = B.pend + (size_t)slot * g.cap;
+    const int h0 = q.head; // head stays in [0, cap), tail in [head, head + cap]
+#pragma unroll
+    for (int t = 0; t < NB; t++) b.node[t] = t < b.k ? pend[ring_at(h0 + t, g.cap)] : 0;
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        const int32_t *Crow = reinterpret_cast<const int32_t *>(node_ptr(pool, g, b.node[t]) + META_DW + 3 * g.AS);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = lane + WAVE * j;
+            b.c[t][j] = (t < b.k && i < g.A) ? Crow[i] : -1;
+        }
+    }
+    q.head += b.k;
+}
+
+template <int NB>
+__device__ __forceinline__ void gc_finish(const GcBatch<NB> &b, const Geo &g, const TreeBufs &B, int slot, PoolState &q, int lane)
+{
+    if (b.k == 0) return;
+    int32_t *pend = B.pend + (size_t)slot * g.cap, *fl = B.freel + (size_t)slot * g.cap;
+    int tl = ring_at(q.tail, g.cap);
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        if (t < b.k) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (WAVE * j < g.A) {
+                    const bool has = b.c[t][j] >= 0;
+                    const unsigned long long m = __ballot(has);
+                    if (has) pend[ring_at(tl + (int)__popcll(m & ((1ull << lane) - 1ull)), g.cap)] = b.c[t][j];
+                    const int n = (int)__popcll(m);
+                    tl = ring_at(tl + n, g.cap);
+                    q.tail += n;
+                }
+            }
+            if (lane == 0) fl[q.n_free] = b.node[t];
+            q.n_free++;
+        }
+    }
+    if (q.head >= g.cap) { q.head -= g.cap; q.tail -= g.cap; } // keep the counters small (tail - head <= cap always)
+}
+
+template <int NB>
+__device__ __forceinline__ void pool_collect(const Geo &g, const TreeBufs &B, int slot, uint32_t *pool, PoolState &q, int lane)
+{
+    GcBatch<NB> b;
+    gc_issue<NB>(b, g, B, slot, pool, q, lane);
+    gc_finish<NB>(b, g, B, slot, q, lane);
+}
+
+// UCTNode creation needs an index: recycled first, then fresh, then whatever the collector can still find
+__device__ __forceinline__ int pool_alloc(const Geo &g, const TreeBufs &B, int slot, uint32_t *pool, PoolState &q, int lane)
+{
+    if (q.n_free == 0 && q.n_nodes >= g.cap) {
+        while (q.n_free == 0 && q.tail > q.head) {
+            pool_collect<4>(g, B, slot, pool, q, lane);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the next batch reads ring entries this one pushed
+        }
+    }
+    if (q.n_free > 0) {
+        q.n_free--;
+        return (B.freel + (size_t)slot * g.cap)[q.n_free]; // wave-uniform load
+    }
+    if (q.n_nodes < g.cap) return q.n_nodes++;
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------
 // numpy pairwise summation on LDS data (<= 256 elements), result broadcast to the wave.
 // Mirrors @TYPE@_pairwise_sum (numpy loops_utils.h.src): 8 strided accumulators per
 // block of <= 128, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), tail added in order.
@@ -248,8 +358,9 @@ __device__ double rng_gamma(uint64_t seed, uint64_t game, uint32_t ply, uint32_t
 __device__ void root_prep(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, Slot *S,
                           uint32_t *pool, float *ldsf, double *ldsd, int lane)
 {
-    NodeMeta rm = load_meta(pool, g, 0);
-    const float *Prow = reinterpret_cast<const float *>(node_ptr(pool, g, 0) + META_DW);
+    const int root = S->root;
+    NodeMeta rm = load_meta(pool, g, root);
+    const float *Prow = reinterpret_cast<const float *>(node_ptr(pool, g, root) + META_DW);
     double *rp = B.root_prior + (size_t)slot * g.AS;
     const int A = g.A;
     int prepped = S->root_prepped, isf64 = S->root_prior_f64;
@@ -311,6 +422,15 @@ __device__ void root_prep(const Geo &g, const SearchCfg &cfg, const TreeBufs &B,
     __syncthreads();
 }
 
+// phase and a step stamp leave in ONE 8-byte store.  The driver pass (move choice, re-root, next search) of step t
+// runs on a second stream NEXT TO k_select of step t: a slot whose search it starts carries stamp t, and k_select(t)
+// -- which may see the slot's old or new phase word -- leaves slots stamped t alone; from step t+1 on (kernel boundary)
+// the slot is a searching slot like any other.
+__device__ __forceinline__ void set_phase_stamped(Slot *S, int phase, int step)
+{
+    *reinterpret_cast<volatile unsigned long long *>(&S->phase) = (unsigned long long)(unsigned)phase | ((unsigned long long)(unsigned)step << 32);
+}
+
 __device__ __forceinline__ int rule_num_reads(const Geo &g, const SearchCfg &cfg, const GState &st)
 {
     // n_searches = min(4*factorial(nb_valid_moves), mcts_num_read), self_play.py:64-65
@@ -327,20 +447,28 @@ __device__ __forceinline__ int rule_num_reads(const Geo &g, const SearchCfg &cfg
 __device__ void begin_search(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, Slot *S,
                              uint32_t *pool, int num_reads, float *ldsf, double *ldsd, int lane)
 {
-    NodeMeta rm = load_meta(pool, g, 0);
+    NodeMeta rm = load_meta(pool, g, S->root);
     if (rm.flags & NF_TERMINAL) { // play_game never searches a terminal root
-        S->phase = PH_IDLE;
         S->sims_left = 0;
+        set_phase_stamped(S, PH_IDLE, cfg.step);
         return;
     }
-    if (num_reads < 0)
+    if (num_reads < 0) {
         num_reads = rule_num_reads(g, cfg, rm.st);
+        // benchmark population (dbaz_selfplay_stagger): the slot's first search is cut short so that the slots'
+        // move boundaries are spread over a whole search instead of all falling into the same step
+        const int ffr = S->ff_reads;
+        if (ffr > 0) {
+            num_reads = min(num_reads, ffr);
+            S->ff_reads = 0;
+        }
+    }
     S->sims_left = num_reads;
     if (rm.flags & NF_EXPANDED) {
         root_prep(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
-        S->phase = num_reads > 0 ? PH_SIMS : PH_READY;
+        set_phase_stamped(S, num_reads > 0 ? PH_SIMS : PH_READY, cfg.step);
     } else {
-        S->phase = PH_EXPAND_ROOT;
+        set_phase_stamped(S, PH_EXPAND_ROOT, cfg.step);
     }
 }
 
@@ -429,8 +557,11 @@ template <int NPL>
 __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, int lane)
 {
     Slot *S = B.slots + slot;
-    const int phase = S->phase;
+    const unsigned long long pw = *reinterpret_cast<volatile const unsigned long long *>(&S->phase); // phase | stamp << 32
+    const int phase = (int)(unsigned)pw;
     if (phase != PH_EXPAND_ROOT && phase != PH_SIMS)
+        return -1;
+    if ((int)(unsigned)(pw >> 32) == cfg.step && cfg.driver_concurrent) // search started by this step's driver pass (see set_phase_stamped)
         return -1;
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
     PathEnt *path = B.path + (size_t)slot * g.dmax;
@@ -440,12 +571,15 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts_mem = 0, ts_tab = 0, ts_ucb = 0, ts_arg = 0, tq0 = 0, tq1 = 0;
     (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts_mem; (void)ts_tab; (void)ts_ucb; (void)ts_arg; (void)tq0; (void)tq1;
     TSTAMP(ts0);
-    int cur = 0, depth = 0, in_move = -1;
-    int n_nodes = S->n_nodes;
+    const int root = S->root;
+    int cur = root, depth = 0, in_move = -1;
+    PoolState q = pool_load(S);
+    GcBatch<GC_PER_STEP> gcb; // the collector's share of this simulation: rows requested now, consumed after the descent
+    gc_issue<GC_PER_STEP>(gcb, g, B, slot, pool, q, lane);
     int Nself = S->root_N;
-    NodeMeta m = load_meta(pool, g, 0);
+    NodeMeta m = load_meta(pool, g, root);
     NodeRows<NPL> R;
-    load_rows<NPL>(R, pool, g, 0, lane);
+    load_rows<NPL>(R, pool, g, root, lane);
     double pbc_cur, sq_cur;
     select_tab(cfg, B, Nself, pbc_cur, sq_cur);
     select_tab_fix(cfg, Nself, pbc_cur, sq_cur);
@@ -487,7 +621,7 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
         for (int j = 0; j < NPL; j++) {
             const int i = lane + WAVE * j;
             const bool in = i < A;
-            const double P = (cur == 0) ? rp[j] : (double)R.P[j];
+            const double P = (cur == root) ? rp[j] : (double)R.P[j];
             const float w = R.W[j];
             const uint32_t ns = R.NS[j];
             const int n = (int)(ns & NS_MASK);
@@ -557,8 +691,8 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
         depth++;
         if (child < 0) {
             // DictWithDefault.__missing__ -> UCTNode(game_state.play(move)), mcts.py:53-54
-            if (n_nodes >= g.cap) { err = DBAZ_EPOOL; depth--; break; }
-            child = n_nodes++;
+            child = pool_alloc(g, B, slot, pool, q, lane);
+            if (child < 0) { err = DBAZ_EPOOL; depth--; break; }
             GState st = m.st;
             int r = gs_play(g, st, bi, nullptr);
             if (r < 0) { err = DBAZ_EILLEGAL; depth--; break; }
@@ -606,6 +740,7 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
         if (lane == 0) { S->error = err; S->phase = PH_ERROR; }
         return -1;
     }
+    gc_finish<GC_PER_STEP>(gcb, g, B, slot, q, lane);
     if (lane == 0) {
         PathEnt pe;
         pe.node = cur; pe.move_in = (int16_t)in_move; pe.to_play = (int16_t)m.st.to_play;
@@ -616,9 +751,9 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
         S->leaf_terminal = (m.flags & NF_TERMINAL) ? 1 : 0;
         S->leaf_result = m.result;
         S->leaf_to_play = m.st.to_play;
-        S->n_nodes = n_nodes;
+        pool_store(q, S);
         S->model = model;
-        if (n_nodes > S->pool_high) S->pool_high = n_nodes;
+        if (q.n_nodes > S->pool_high) S->pool_high = q.n_nodes;
     }
     if (!(m.flags & NF_TERMINAL)) {
         // get_features of the leaf as float32 planes (nn_batch_builder + nn.py:157)
@@ -634,6 +769,7 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
             // lanes 0..TT_PROBES-1 read the probe window; a candidate is verified against the live tree
             const uint64_t h = formula_hash(m.st);
             const unsigned long long *tt = B.tt + (size_t)slot * ((size_t)B.tt_mask + 1);
+            unsigned long long *ttw = B.tt + (size_t)slot * ((size_t)B.tt_mask + 1);
             unsigned long long ent = 0;
             if (lane < TT_PROBES) ent = tt[((unsigned)h + (unsigned)lane) & (unsigned)B.tt_mask];
             unsigned long long cand = __ballot(lane < TT_PROBES && ent != 0ull && (ent >> 40) == (h >> 40));
@@ -642,11 +778,15 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
                 const int pl = __ffsll((long long)cand) - 1;
                 cand &= cand - 1;
                 const int idx = (int)(unsigned)__shfl(ent, pl);
-                if (idx >= 0 && idx < n_nodes && idx != cur) {
+                if (idx >= 0 && idx < q.n_nodes && idx != cur) {
                     const NodeMeta tm = load_meta(pool, g, idx);
                     if ((tm.flags & NF_EXPANDED) && !(tm.flags & NF_TERMINAL) && tm.st.e0 == m.st.e0 && tm.st.e1 == m.st.e1 &&
-                        tm.st.e2 == m.st.e2 && tm.st.e3 == m.st.e3 && tt_mover_b2c(tm.st) == mb)
+                        tm.st.e2 == m.st.e2 && tm.st.e3 == m.st.e3 && tt_mover_b2c(tm.st) == mb) {
                         hit = idx;
+                        // still in use: stamp the entry with the current epoch (old epochs are the preferred victims)
+                        if (lane == 0)
+                            ttw[((unsigned)h + (unsigned)pl) & (unsigned)B.tt_mask] = tt_entry(h, tt_epoch_byte(S->tt_epoch), idx);
+                    }
                 }
             }
             if (hit >= 0) need_eval = -1;
@@ -681,13 +821,6 @@ __global__ void __launch_bounds__(WAVE * SELECT_WAVES) k_select(Geo g, SearchCfg
     if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(B.n_eval + threadIdx.x, s_cnt[threadIdx.x]);
     __syncthreads();
     if (my >= 0) (model ? B.eval_list2 : B.eval_list)[s_base[model] + my] = slot;
-}
-
-// phase and the step stamp leave in ONE 8-byte store: the driver kernel runs on a second stream next to this step's
-// expand/backup and must not take a slot that turned PH_READY during the very step it is running in
-__device__ __forceinline__ void set_phase_stamped(Slot *S, int phase, int step)
-{
-    *reinterpret_cast<volatile unsigned long long *>(&S->phase) = (unsigned long long)(unsigned)phase | ((unsigned long long)(unsigned)step << 32);
 }
 
 // ------------------------------------------------------------------------------------
@@ -799,123 +932,26 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
 }
 
 // ------------------------------------------------------------------------------------
-// init_mcts_tree (mcts.py:163-180): re-root with in-place subtree compaction
+// init_mcts_tree (mcts.py:163-180): O(1) re-root.  reuse_tree: the chosen child becomes the root where it
+// lies (its subtree keeps its node indices, so transposition entries stay valid), the old root -- link to
+// the kept child cut -- goes onto the collector's ring.  Otherwise the whole pool is dropped.
 // ------------------------------------------------------------------------------------
-// Keeps the subtree below `newroot`, sliding kept nodes down in index order (children are
-// always created after their parent, so index order is a topological order and a kept
-// node never moves past an unmoved kept node).  Returns the number of kept nodes.
-__device__ int compact_subtree(const Geo &g, uint32_t *pool, int32_t *remap, uint64_t *marks /*LDS*/,
-                               int newroot, int n_nodes, int lane)
+__device__ __forceinline__ void pool_reset(Slot *S)
 {
-    int kept = 0;
-    // pass 1: reachability + new indices
-    for (int base = newroot; base < n_nodes; base += WAVE) {
-        int k = base + lane;
-        bool active = k < n_nodes;
-        int parent = -1;
-        if (active)
-            parent = (int)node_ptr(pool, g, k)[8];
-        bool mk = active && (k == newroot);
-        if (active && parent >= newroot && parent < base) {
-            int rel = parent - newroot;
-            mk = (marks[rel >> 6] >> (rel & 63)) & 1ull;
-        }
-        bool inchunk = active && parent >= base && k != newroot;
-        for (;;) {
-            uint64_t bal = __ballot(mk);
-            bool nm = mk || (inchunk && ((bal >> (parent - base)) & 1ull));
-            uint64_t ch = __ballot(nm != mk);
-            mk = nm;
-            if (!ch) break;
-        }
-        uint64_t bal = __ballot(mk);
-        if (lane == 0)
-            marks[(base - newroot) >> 6] = bal;
-        __syncthreads();
-        int idx = kept + __popcll(bal & ((1ull << lane) - 1ull));
-        if (active)
-            remap[k] = mk ? idx : -1;
-        kept += __popcll(bal);
-    }
-    __syncthreads();
-    __threadfence_block();
-    // pass 2: move kept nodes (ascending), fixing parent and child indices.  CB nodes per iteration: ALL their
-    // dwords and remap look-ups are in flight together (one wave, so memory latency is the whole cost), and nothing is
-    // stored before every source of the batch has been read -- a destination (rank r) never lies above its source, so
-    // within a batch only sources of that batch can be overwritten, and later kept nodes sit above every destination.
-    const int ndw = g.node_dw;
-    const int c_lo = META_DW + 3 * g.AS, c_hi = META_DW + 4 * g.AS;
-    constexpr int CB = 8;          // nodes per batch
-    constexpr int CD = 8;          // dwords per lane per node (node_dw <= 64 * CD = 512: A <= 124; larger boards loop)
-    int base = newroot;
-    uint64_t bal = base < n_nodes ? marks[0] : 0ull;
-    for (;;) {
-        int ks[CB], nb = 0;
-#pragma unroll
-        for (int q = 0; q < CB; q++) { // next kept node indices (wave-uniform bookkeeping, constant subscripts only)
-            ks[q] = -1;
-            while (!bal && base + WAVE < n_nodes) {
-                base += WAVE;
-                bal = marks[(base - newroot) >> 6];
-            }
-            if (bal) {
-                const int b = __ffsll((long long)bal) - 1;
-                bal &= bal - 1;
-                ks[q] = base + b;
-                nb = q + 1;
-            }
-        }
-        if (nb == 0) break;
-        for (int dw0 = 0; dw0 < ndw; dw0 += CD * WAVE) {
-            uint32_t v[CB][CD];
-#pragma unroll
-            for (int q = 0; q < CB; q++)
-                if (q < nb) {
-                    const uint32_t *src = node_ptr(pool, g, ks[q]);
-#pragma unroll
-                    for (int u = 0; u < CD; u++) {
-                        const int dw = dw0 + u * WAVE + lane;
-                        v[q][u] = dw < ndw ? src[dw] : 0u;
-                    }
-                }
-#pragma unroll
-            for (int q = 0; q < CB; q++)
-                if (q < nb) {
-#pragma unroll
-                    for (int u = 0; u < CD; u++) {
-                        const int dw = dw0 + u * WAVE + lane;
-                        if (dw < ndw) {
-                            if (dw == 8)
-                                v[q][u] = (ks[q] == newroot) ? 0xFFFFFFFFu : (uint32_t)remap[(int)v[q][u]];
-                            else if (dw >= c_lo && dw < c_hi && (int)v[q][u] >= 0)
-                                v[q][u] = (uint32_t)remap[(int)v[q][u]];
-                        }
-                    }
-                }
-#pragma unroll
-            for (int q = 0; q < CB; q++)
-                if (q < nb) {
-                    uint32_t *dst = node_ptr(pool, g, remap[ks[q]]);
-#pragma unroll
-                    for (int u = 0; u < CD; u++) {
-                        const int dw = dw0 + u * WAVE + lane;
-                        if (dw < ndw) dst[dw] = v[q][u];
-                    }
-                }
-            if (dw0 + CD * WAVE < ndw) __threadfence_block(); // (boards with more than 512 dwords per node)
-        }
-        if (nb < CB) break;
-    }
-    __syncthreads();
-    return kept;
+    S->root = 0;
+    S->n_nodes = 1;
+    S->n_free = 0;
+    S->pend_head = 0;
+    S->pend_tail = 0;
 }
 
 // re-root slot on `move`; returns 0 or an error code.  wave-uniform.
 __device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32_t *pool, int move,
-                      int reuse, uint64_t *marks, int lane)
+                      int reuse, int lane)
 {
-    NodeMeta rm = load_meta(pool, g, 0);
-    uint32_t *nd0 = node_ptr(pool, g, 0);
+    const int root = S->root;
+    NodeMeta rm = load_meta(pool, g, root);
+    uint32_t *nd0 = node_ptr(pool, g, root);
     if (move < 0 || move >= g.A)
         return DBAZ_EILLEGAL;
     int child = (int)nd0[META_DW + 3 * g.AS + move];
@@ -935,39 +971,26 @@ __device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32
     }
     __syncthreads();
     if (reuse && child >= 0) {
-        int32_t *remap = B.remap + (size_t)slot * g.cap;
-        int kept = compact_subtree(g, pool, remap, marks, child, S->n_nodes, lane);
-        S->n_nodes = kept;
+        const int tail = S->pend_tail;
+        if (lane == 0) {
+            nd0[META_DW + 3 * g.AS + move] = 0xFFFFFFFFu;           // the kept subtree is no child of the dropped root
+            node_ptr(pool, g, child)[8] = 0xFFFFFFFFu;               // new root: parent = None
+            (B.pend + (size_t)slot * g.cap)[ring_at(tail, g.cap)] = root;
+        }
+        S->pend_tail = tail + 1;
+        S->root = child;
         S->deepness_correction = child_deep;
         S->tree_size = carried;
-        if (B.tt) {
-            // the kept nodes were renumbered: enter the expanded ones into the table under the new epoch (one node
-            // per lane; two lanes racing for one entry just leave one of them cached)
-            const unsigned ep = tt_epoch_byte(S->tt_epoch + 1);
-            unsigned long long *tt = B.tt + (size_t)slot * ((size_t)B.tt_mask + 1);
-            for (int j = lane; j < kept; j += WAVE) {
-                const NodeMeta km = load_meta(pool, g, j);
-                if ((km.flags & NF_EXPANDED) && !(km.flags & NF_TERMINAL)) {
-                    const uint64_t h = formula_hash(km.st);
-                    int victim = (int)((h >> 20) & (TT_PROBES - 1));
-                    for (int q = TT_PROBES - 1; q >= 0; q--) {
-                        const unsigned long long e0 = tt[((unsigned)h + (unsigned)q) & (unsigned)B.tt_mask];
-                        if (e0 == 0ull || ((unsigned)(e0 >> 32) & 0xFFu) != ep) victim = q;
-                    }
-                    tt[((unsigned)h + (unsigned)victim) & (unsigned)B.tt_mask] = tt_entry(h, ep, j);
-                }
-            }
-        }
     } else if (reuse) {
-        // children[move] did not exist: a fresh, unexpanded node becomes the root
+        // children[move] did not exist: a fresh, unexpanded node becomes the root; nothing else survives
+        pool_reset(S);
         init_node(pool, g, 0, st, -1, move, child_deep, lane);
-        S->n_nodes = 1;
         S->deepness_correction = child_deep;
         S->tree_size = carried;
     } else {
         // create_root_uct_node(child.game_state); next_node.move = move
+        pool_reset(S);
         init_node(pool, g, 0, st, -1, move, 1, lane);
-        S->n_nodes = 1;
         S->deepness_correction = 0;
         S->tree_size = 0;
     }
@@ -978,7 +1001,7 @@ __device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32
     S->root_prior_f64 = 0;
     S->max_deepness = 0;
     S->terminal_count = 0;
-    S->tt_epoch = S->tt_epoch + 1; // node indices changed: every table entry of this game is now stale
+    S->tt_epoch = S->tt_epoch + 1; // entries of older moves become the preferred victims (they stay valid while their node lives)
     __syncthreads();
     return 0;
 }
@@ -1015,7 +1038,7 @@ __device__ void fresh_game(const Geo &g, const SearchCfg &cfg, const TreeBufs &B
         S->ff_plies = 0;
     }
     init_node(pool, g, 0, st, -1, -1, 1, lane);
-    S->n_nodes = 1;
+    pool_reset(S);
     S->root_N = 0;
     S->root_W = 0.0f;
     S->root_prepped = 0;
@@ -1029,6 +1052,7 @@ __device__ void fresh_game(const Geo &g, const SearchCfg &cfg, const TreeBufs &B
     S->game_idx = game_idx;
     S->temperature = 1.0;
     S->phase = PH_IDLE;
+    S->sel_step = 0; // no leaf pending (step numbers start at 1)
     S->tt_epoch = S->tt_epoch + 1;
     (void)plies;
     __syncthreads();
@@ -1048,6 +1072,7 @@ __global__ void __launch_bounds__(WAVE) k_set_positions(Geo g, SearchCfg cfg, Tr
             if (gs_play(g, st, moves[i], nullptr) < 0) { err = DBAZ_EILLEGAL; break; }
     }
     S->ff_plies = 0;
+    S->ff_reads = 0;
     fresh_game(g, cfg, B, slot, S, pool, slot, lane);
     init_node(pool, g, 0, st, -1, -1, 1, lane);
     if (lane == 0) {
@@ -1062,7 +1087,6 @@ __global__ void __launch_bounds__(WAVE) k_set_positions(Geo g, SearchCfg cfg, Tr
 __global__ void __launch_bounds__(WAVE) k_advance_manual(Geo g, SearchCfg cfg, TreeBufs B, const int32_t *moves,
                                                          int reuse)
 {
-    extern __shared__ uint64_t marks[];
     const int slot = blockIdx.x, lane = threadIdx.x;
     Slot *S = B.slots + slot;
     if (S->phase == PH_ERROR || S->game_idx < 0)
@@ -1071,7 +1095,7 @@ __global__ void __launch_bounds__(WAVE) k_advance_manual(Geo g, SearchCfg cfg, T
     if (mv < 0)
         return;
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
-    int err = reroot(g, B, slot, S, pool, mv, reuse, marks, lane);
+    int err = reroot(g, B, slot, S, pool, mv, reuse, lane);
     if (lane == 0) {
         if (err) { S->error = err; S->phase = PH_ERROR; }
         else { S->phase = PH_IDLE; S->move_idx += 1; }
@@ -1084,7 +1108,7 @@ __global__ void __launch_bounds__(WAVE) k_advance_manual(Geo g, SearchCfg cfg, T
 __device__ bool try_emit(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32_t *pool, int lane)
 {
     // rows of the finished game -> output buffer, z per row (self_play.py:105-112)
-    NodeMeta rm = load_meta(pool, g, 0); // terminal root
+    NodeMeta rm = load_meta(pool, g, S->root); // terminal root
     const int n = S->n_rows;
     int base = 0;
     if (lane == 0) {
@@ -1186,14 +1210,11 @@ __global__ void __launch_bounds__(WAVE) k_selfplay_start(Geo g, SearchCfg cfg, T
 // (the slots come from k_driver_scan's list: a step in which no slot needs the driver costs two tiny launches instead
 // of one workgroup per game squeezing in between the network's workgroups)
 __device__ void advance_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, float *ldsf, double *ldsd,
-                            uint64_t *marks, int lane)
+                            int lane)
 {
     Slot *S = B.slots + slot;
-    const unsigned long long pw = *reinterpret_cast<volatile const unsigned long long *>(&S->phase); // phase | ready_at << 32
-    const int phase = (int)(unsigned)pw, ready_at = (int)(unsigned)(pw >> 32);
+    const int phase = S->phase;
     if (phase != PH_READY && phase != PH_EMIT)
-        return;
-    if (phase == PH_READY && ready_at == cfg.step) // became ready in THIS step: its expand/backup wave may still be writing
         return;
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
     const int A = g.A, F = 3 * g.HW, rcap = g.E + 1;
@@ -1202,8 +1223,9 @@ __device__ void advance_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &
             next_game_or_idle(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
         return;
     }
-    NodeMeta rm = load_meta(pool, g, 0);
-    const uint32_t *NS0 = node_ptr(pool, g, 0) + META_DW + 2 * g.AS;
+    const int root = S->root;
+    NodeMeta rm = load_meta(pool, g, root);
+    const uint32_t *NS0 = node_ptr(pool, g, root) + META_DW + 2 * g.AS;
     // ---- get_next_move (self_play.py:27-35) ----
     int vmax = 0;
     long long vsum = 0;
@@ -1279,14 +1301,14 @@ __device__ void advance_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &
     }
     __syncthreads();
     // ---- init_mcts_tree ----
-    int err = reroot(g, B, slot, S, pool, mv, cfg.reuse_tree, marks, lane);
+    int err = reroot(g, B, slot, S, pool, mv, cfg.reuse_tree, lane);
     if (err) {
         if (lane == 0) { S->error = err; S->phase = PH_ERROR; }
         return;
     }
     S->move_idx = ply + 1;
     if (lane == 0) atomicAdd((unsigned long long *)B.moves_played, 1ull);
-    NodeMeta nm = load_meta(pool, g, 0);
+    NodeMeta nm = load_meta(pool, g, S->root);
     if (nm.flags & NF_TERMINAL) {
         if (try_emit(g, B, slot, S, pool, lane))
             next_game_or_idle(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
@@ -1297,15 +1319,14 @@ __device__ void advance_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &
     start_move_search(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
 }
 
-// which slots need the driver: finished reads (not of this very step, see set_phase_stamped) or a blocked emit
+// which slots need the driver: finished reads or a blocked emit (the pass runs after the previous step's expand/backup)
 __global__ void __launch_bounds__(256) k_driver_scan(SearchCfg cfg, TreeBufs B, int n_slots)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool need = false;
     if (i < n_slots) {
-        const unsigned long long pw = *reinterpret_cast<volatile const unsigned long long *>(&B.slots[i].phase);
-        const int phase = (int)(unsigned)pw, ready_at = (int)(unsigned)(pw >> 32);
-        need = phase == PH_EMIT || (phase == PH_READY && ready_at != cfg.step);
+        const int phase = B.slots[i].phase;
+        need = phase == PH_EMIT || phase == PH_READY;
     }
     const unsigned long long m = __ballot(need);
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1319,11 +1340,10 @@ __global__ void __launch_bounds__(WAVE) k_advance_auto(Geo g, SearchCfg cfg, Tre
 {
     __shared__ float ldsf[DBAZ_MAX_A];
     __shared__ double ldsd[DBAZ_MAX_A];
-    extern __shared__ uint64_t marks[];
     const int lane = threadIdx.x;
     const int n = *B.drv_count;
     for (int li = blockIdx.x; li < n; li += gridDim.x) {
-        advance_one(g, cfg, B, B.drv_list[li], ldsf, ldsd, marks, lane);
+        advance_one(g, cfg, B, B.drv_list[li], ldsf, ldsd, lane);
         __syncthreads();
     }
 }
@@ -1339,8 +1359,8 @@ __global__ void k_get_roots(Geo g, TreeBufs B, int n_slots, double *priors, floa
     if (slot >= n_slots) return;
     Slot *S = B.slots + slot;
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
-    NodeMeta rm = load_meta(pool, g, 0);
-    const uint32_t *nd = node_ptr(pool, g, 0);
+    NodeMeta rm = load_meta(pool, g, S->root);
+    const uint32_t *nd = node_ptr(pool, g, S->root);
     const int A = g.A;
     for (int i = lane; i < A; i += WAVE) {
         uint32_t ns = nd[META_DW + 2 * g.AS + i];
@@ -1399,6 +1419,40 @@ __global__ void k_get_leaves(Geo g, TreeBufs B, int n_slots, int16_t *leaf_x, ui
         need_eval[slot] = need ? 1 : 0;
         if (active) atomicAdd(n_active, 1);
     }
+}
+
+// Slot array -> SlotSummary (out must be zeroed except first_error_slot = 0x7fffffff)
+__global__ void __launch_bounds__(256) k_slot_summary(TreeBufs B, int n_slots, SlotSummary *out)
+{
+    unsigned long long ns = 0, ne = 0, nh = 0, nt = 0, sp = 0;
+    int active = 0, error = 0, blocked = 0, high = 0, ferr = 0x7fffffff;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x) {
+        const Slot &S = B.slots[i];
+        ns += (unsigned long long)S.n_search; ne += (unsigned long long)S.n_eval; nh += (unsigned long long)S.n_hit;
+        nt += (unsigned long long)S.n_term; sp += (unsigned long long)S.sum_path;
+        const int ph = S.phase;
+        if (ph == PH_ERROR) { error++; ferr = min(ferr, i); }
+        else if (S.game_idx >= 0 && ph != PH_IDLE) active++;
+        if (ph == PH_EMIT) blocked++;
+        high = max(high, S.pool_high);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        ns += __shfl_xor(ns, o); ne += __shfl_xor(ne, o); nh += __shfl_xor(nh, o); nt += __shfl_xor(nt, o); sp += __shfl_xor(sp, o);
+        active += __shfl_xor(active, o); error += __shfl_xor(error, o); blocked += __shfl_xor(blocked, o);
+        high = max(high, __shfl_xor(high, o)); ferr = min(ferr, __shfl_xor(ferr, o));
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        atomicAdd(&out->n_search, ns); atomicAdd(&out->n_eval, ne); atomicAdd(&out->n_hit, nh); atomicAdd(&out->n_term, nt);
+        atomicAdd(&out->sum_path, sp);
+        atomicAdd(&out->active, active); atomicAdd(&out->error, error); atomicAdd(&out->blocked, blocked);
+        atomicMax(&out->pool_high, high);
+        if (ferr != 0x7fffffff) atomicMin(&out->first_error_slot, ferr);
+    }
+}
+// second pass (only when an error was seen): the code of the lowest failing slot
+__global__ void k_slot_error_code(TreeBufs B, SlotSummary *out)
+{
+    if (out->first_error_slot != 0x7fffffff) out->first_error_code = B.slots[out->first_error_slot].error;
 }
 
 __global__ void k_count_active(TreeBufs B, int n_slots, int32_t *out /*[3]: searching, ready, error*/)
@@ -1460,8 +1514,6 @@ __global__ void k_rules(Geo g, int op, int n, uint64_t *edges, int16_t *b2c2, in
 // ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
-static size_t marks_bytes(const Geo &g) { return (size_t)((g.cap + 63) / 64 + 1) * sizeof(uint64_t); }
-
 void tree_launch_search_begin(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots,
                               const int32_t *num_reads_dev)
 {
@@ -1488,7 +1540,7 @@ void tree_launch_set_positions(hipStream_t s, const Geo &g, const SearchCfg &c, 
 void tree_launch_advance_manual(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots,
                                 const int32_t *moves_dev, int reuse)
 {
-    hipLaunchKernelGGL(k_advance_manual, dim3(n_slots), dim3(WAVE), marks_bytes(g), s, g, c, B, moves_dev, reuse);
+    hipLaunchKernelGGL(k_advance_manual, dim3(n_slots), dim3(WAVE), 0, s, g, c, B, moves_dev, reuse);
 }
 void tree_launch_selfplay_start(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
 {
@@ -1498,7 +1550,7 @@ void tree_launch_advance_auto(hipStream_t s, const Geo &g, const SearchCfg &c, c
 {
     (void)hipMemsetAsync(B.drv_count, 0, 4, s);
     hipLaunchKernelGGL(k_driver_scan, dim3((n_slots + 255) / 256), dim3(256), 0, s, c, B, n_slots);
-    hipLaunchKernelGGL(k_advance_auto, dim3(n_slots < 128 ? n_slots : 128), dim3(WAVE), marks_bytes(g), s, g, c, B);
+    hipLaunchKernelGGL(k_advance_auto, dim3(n_slots < 1024 ? n_slots : 1024), dim3(WAVE), 0, s, g, c, B);
 }
 void tree_launch_get_roots(hipStream_t s, const Geo &g, const TreeBufs &B, int n_slots, double *priors, float *tv,
                            int32_t *nv, int32_t *changed, int32_t *stats, float *q, float *root_tv, int32_t *root_nv,
@@ -1516,6 +1568,13 @@ void tree_launch_get_leaves(hipStream_t s, const Geo &g, const TreeBufs &B, int 
 void tree_launch_count_active(hipStream_t s, const TreeBufs &B, int n_slots, int32_t *out3)
 {
     hipLaunchKernelGGL(k_count_active, dim3((n_slots + 255) / 256), dim3(256), 0, s, B, n_slots, out3);
+}
+void tree_launch_slot_summary(hipStream_t s, const TreeBufs &B, int n_slots, SlotSummary *out_dev)
+{
+    int blocks = (n_slots + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(k_slot_summary, dim3(blocks), dim3(256), 0, s, B, n_slots, out_dev);
+    hipLaunchKernelGGL(k_slot_error_code, dim3(1), dim3(1), 0, s, B, out_dev);
 }
 void tree_launch_rules(hipStream_t s, const Geo &g, int op, int n, uint64_t *edges, int16_t *b2c2, int8_t *to_play,
                        int8_t *just_played, const int32_t *moves, int8_t *n_closed, int8_t *closed_lc, uint8_t *valid,

@@ -242,6 +242,12 @@ class Engine:
         assert pl.shape == (self.n_slots,)
         self._ck(self._L.dbaz_selfplay_fastforward(self.h, _p(pl)))
 
+    def selfplay_stagger(self, first_reads):
+        """Benchmark population: read budget of each slot's first search (0 = the driver rule)."""
+        fr = np.ascontiguousarray(first_reads, np.int32)
+        assert fr.shape == (self.n_slots,)
+        self._ck(self._L.dbaz_selfplay_stagger(self.h, _p(fr)))
+
     def selfplay_start(self, n_games, first_game_idx=0):
         self._ck(self._L.dbaz_selfplay_start(self.h, int(n_games), int(first_game_idx)))
 

@@ -177,6 +177,11 @@ int dbaz_selfplay_script(dbaz_engine *e, int64_t game_idx, const int16_t *moves,
 /* synthetic mid-game population for benchmarking: slot i is advanced by plies[i]
  * uniformly random legal moves before its first search. */
 int dbaz_selfplay_fastforward(dbaz_engine *e, const int32_t *plies);
+/* benchmark population, second knob: the FIRST search of slot i is cut to min(rule, first_reads[i]) reads
+ * (0 = the rule), so that the slots' move boundaries -- re-rooting, tree reuse, game turnover -- are spread over a
+ * whole search instead of falling into the same steps.  Like dbaz_selfplay_fastforward it applies to the next
+ * dbaz_selfplay_start only and is never used on the parity paths. */
+int dbaz_selfplay_stagger(dbaz_engine *e, const int32_t *first_reads);
 int dbaz_step(dbaz_engine *e, int32_t k);             /* k simulation steps, asynchronous */
 /* until all games are finished, max_steps (if > 0) are done, or every remaining slot is
  * blocked on a full output buffer (counters.blocked_slots == active_slots: fetch and call again) */
