@@ -84,3 +84,86 @@ def test_resnet_full_batch_network_consistency():
     pr, vr = nn_ref.predict_sync(m, X[:64])
     assert np.abs(p[:64] - pr).max() < 1e-4 and np.abs(v[:64] - vr).max() < 1e-4
     e.close()
+
+
+# ---------------------------------------------------------------- BASELINE configs[4], per-GPU share
+def test_config4_9x9_2048_games_1600_sims_steps():
+    """9x9 (A = 200, 3264-byte nodes, 16 020-node pools), 2048 concurrent games, 1600 sims/move -- one GPU's share
+    of configs[4] -- for a bounded number of steps, first searches staggered so that re-rooting with tree reuse
+    happens inside the window.  Bookkeeping identities of mcts.py / self_play.py per slot:
+      still in the first search:   sum(child visits) == root visits - 1   (the expanding search visits no child)
+      after a re-root (reuse):     sum(child visits) == tree_size - 1 + root visits   (mcts.py:163-180: the kept
+                                   child arrives with its own visits; its first visit expanded it)"""
+    from dotsboxesaz_amd.engine import Engine
+    K, n = 150, 2048
+    e = Engine(9, 9, n, mcts_num_read=1600, noise=(0.8, 0.25), evaluator="formula", seed=5)
+    first = (np.arange(n) * 7) % 100 + 1
+    first[::4] = 0  # a quarter of the slots keep the full first search
+    e.selfplay_stagger(first)
+    e.selfplay_start(1 << 30, 0)
+    e.step(K)
+    c = e.counters()
+    assert c["error_slots"] == 0
+    r = e.roots()
+    moved = r["stats"][:, 1] > 0  # tree_size > 0: re-rooted with a kept subtree
+    assert moved.sum() > n // 2 and (~moved).sum() >= n // 4
+    # a slot skips the step in which the driver pass starts its next search
+    assert n * K - 4 * n <= c["expansions"] <= n * K
+    vs = r["visits"].sum(1)
+    assert (vs[~moved] == r["root_nv"][~moved] - 1).all()
+    assert (vs[moved] == r["stats"][moved, 1] - 1 + r["root_nv"][moved]).all()
+    assert (r["root_nv"][~moved] == K).all()
+    assert np.isfinite(r["total_value"]).all() and np.isfinite(r["q"]).all()
+    st = e.root_states()
+    valid = e.rules_valid_moves(st)
+    assert (r["visits"][~valid] == 0).all() and (r["priors"][~valid] == 0).all()
+    assert (r["stats"][:, 0] >= 0).all() and (r["stats"][:, 0] <= e.E + 1).all()          # max_deepness
+    assert c["pool_high_water"] <= K + 2 and c["moves_played"] >= moved.sum()
+    e.close()
+
+
+def test_config4_9x9_complete_games_vs_oracle_rules():
+    """A few complete 9x9 games at 1600 sims/move (176+ plies each): every row replayed with the oracle rules
+    (legality, features, player, z), read budget rule, pool high-water and depth bounds."""
+    from dotsboxesaz_amd.engine import Engine
+    n_games = 6
+    e = Engine(9, 9, n_games, mcts_num_read=1600, noise=(0.8, 0.25), evaluator="formula", seed=21)
+    e.selfplay_start(n_games, 0)
+    e.run()
+    c = e.counters()
+    assert c["games_finished"] == n_games and c["error_slots"] == 0 and c["active_slots"] == 0
+    got = e.fetch_samples()
+    check_rows(got, 9, 9, n_games)
+    cap = 10 * (1600 + 2)
+    assert 1600 < c["pool_high_water"] <= cap
+    # deepest node below a root cannot lie beyond the end of the game
+    remaining = e.E - got["move_idx"].astype(np.int32)
+    assert (got["max_deepness"] >= 0).all() and (got["max_deepness"] <= remaining + 1).all()
+    assert (got["tree_size"][got["move_idx"] == 0] == 0).all() and (got["tree_size"] <= 1601 * got["move_idx"].astype(np.int64)).all()  # carried visits accumulate over the moves
+    per_game = c["expansions"] / n_games
+    assert 150 * 1600 < per_game <= (e.E + 1) * 1601
+    e.close()
+
+
+def test_config4_9x9_network_steps():
+    """The fused trunk on 10x10 images (2 samples per workgroup, 13 position tiles) inside the self-play step at 2048
+    slots: every expansion is a network evaluation, a cache hit or a terminal leaf."""
+    import torch
+    from oracle import nn_ref
+    from dotsboxesaz_amd.engine import Engine
+    torch.manual_seed(0)
+    m = nn_ref.ResNetZeroRef(9, 9, 64, 4)
+    nn_ref.randomize_bn(m, 2)
+    K, n = 12, 2048
+    e = Engine(9, 9, n, mcts_num_read=1600, noise=(0.8, 0.25), evaluator="resnet", nn_precision=1, seed=3)
+    e.load_state_dict(m.state_dict(), "resnet", 64, 4, 16, 8)
+    e.selfplay_fastforward((np.arange(n) * 37) % 120)
+    e.selfplay_start(1 << 30, 0)
+    e.step(K)
+    c = e.counters()
+    assert c["error_slots"] == 0 and c["expansions"] == n * K
+    assert c["nn_evals"] + c["cache_hits"] + c["terminal_leaves"] == c["expansions"] and c["nn_evals"] > n * K // 2
+    r = e.roots()
+    assert (r["root_nv"] == K).all() and (r["visits"].sum(1) == K - 1).all()
+    assert np.isfinite(r["total_value"]).all() and np.allclose(r["priors"].sum(1), 1.0, atol=0.26)
+    e.close()

@@ -42,14 +42,19 @@ def test_golden_full_size(golden_nn, tag, rows, cols):
     nn_ref.randomize_bn(m, 3)
     e = engine_for(rows, cols, m)
     p, v = e.predict(g[tag + "_X"])
-    cs = nn_ref.state_dict_checksum(m)
-    if abs(cs - float(g[tag + "_checksum"])) <= 1e-6 * cs:
-        assert np.abs(p - g[tag + "_p"]).max() < TOL
-        assert np.abs(v - g[tag + "_v"]).max() < TOL
+    e.close()
     # always: against the torch fp32 restatement with the very same weights
     pr, vr = nn_ref.predict_sync(m, g[tag + "_X"])
     assert np.abs(p - pr).max() < TOL and np.abs(v - vr).max() < TOL
-    e.close()
+    # the reference's own outputs: the fixture holds them for the weights ITS run drew from the seed (6 MB of
+    # weights are not committed); a torch build with another RNG stream cannot regenerate them -- say so, loudly
+    cs = nn_ref.state_dict_checksum(m)
+    if abs(cs - float(g[tag + "_checksum"])) > 1e-6 * cs:
+        pytest.skip("seed-regenerated weights differ from the fixture's (checksum %r vs %r): golden comparison of %s "
+                    "not possible with this torch build; the torch-restatement comparison above passed"
+                    % (cs, float(g[tag + "_checksum"]), tag))
+    assert np.abs(p - g[tag + "_p"]).max() < TOL
+    assert np.abs(v - g[tag + "_v"]).max() < TOL
 
 
 @pytest.mark.parametrize("rows,cols,ch,nb,n", [(6, 6, 64, 3, 1), (6, 6, 64, 3, 3), (6, 6, 64, 3, 4), (6, 6, 64, 3, 5),
@@ -155,10 +160,7 @@ def test_simplenn_golden_and_torch(golden_nn, precision):
     m = nn_ref.SimpleNNRef()
     nn_ref.randomize_bn(m, 3)
     e = simple_engine(m, precision)
-    p, v = e.predict(g["simple_X"])
-    cs = nn_ref.state_dict_checksum(m)
-    if abs(cs - float(g["simple_checksum"])) <= 1e-6 * cs:
-        assert np.abs(p - g["simple_p"]).max() < TOL and np.abs(v - g["simple_v"]).max() < TOL
+    pg, vg = e.predict(g["simple_X"])
     rng = np.random.RandomState(1)
     X = rng.randint(0, 2, size=(77, 3, 4, 4)).astype(np.float32)
     X[:, 2] = rng.randint(-1, 10, size=(77, 1, 1))
@@ -170,6 +172,11 @@ def test_simplenn_golden_and_torch(golden_nn, precision):
     p1, v1 = e.predict(X[5:6])
     assert np.array_equal(p1[0], p[5]) and np.array_equal(v1[0], v[5])
     e.close()
+    cs = nn_ref.state_dict_checksum(m)
+    if abs(cs - float(g["simple_checksum"])) > 1e-6 * cs:  # see test_golden_full_size
+        pytest.skip("seed-regenerated SimpleNN weights differ from the fixture's (checksum %r vs %r): golden comparison "
+                    "not possible with this torch build; the torch-restatement comparison passed" % (cs, float(g["simple_checksum"])))
+    assert np.abs(pg - g["simple_p"]).max() < TOL and np.abs(vg - g["simple_v"]).max() < TOL
 
 
 def test_simplenn_rejects_other_boards_and_plays():
