@@ -951,6 +951,7 @@ extern "C" int dbaz_get_counters(dbaz_engine *e, dbaz_counters *out)
     out->ms_nn_tower = e->ms_nn_tower;
     out->ms_tree = e->ms_total - e->ms_nn_tower;
     out->nn_launches = e->nn_launches;
+    out->f32_fallback_evals = (int32_t)std::min<long long>(nn_fallback_evals(e->nns[0]) + nn_fallback_evals(e->nns[1]), 0x7fffffff);
     if (nn_overflowed(e->nns[0]) || nn_overflowed(e->nns[1]))
         return set_error(e, DBAZ_EDEVICE, "nn_precision=1: an activation left the f16 range; use nn_precision=0 for this network");
     return DBAZ_OK;

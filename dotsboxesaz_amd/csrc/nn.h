@@ -22,3 +22,5 @@ double nn_flops_per_sample(const NNState *nn);
 const char *nn_tower_kernel_name(const NNState *nn);
 // f16x3 mode: non-zero once an activation exceeded f16's range (results invalid: use precision 0)
 int nn_overflowed(NNState *nn);
+// f16x3 mode of ResNetZero: samples whose f16x3 evaluation left f16's range and were redone in exact f32
+long long nn_fallback_evals(NNState *nn);

@@ -57,7 +57,9 @@ struct NNState {
     float *tw = nullptr, *tb = nullptr;         // tower: packed weights [2*blocks][C*C*9], bias [2*blocks][C]
     float *tosc = nullptr;                      // f16x3: per-layer output scale 2^-(sw+ACT_SHIFT)
     unsigned long long *stamp_out = nullptr;    // diagnostic build (-DDBAZ_STAMP) only
-    int *overflow = nullptr;                    // f16x3: set when an activation left f16's range
+    int *overflow = nullptr;                    // f16x3: [0] set when an activation left f16's range, [1] samples re-evaluated in exact f32
+    int *ovf_flags = nullptr;                   // f16x3: per sample of the batch, 1 = its workgroup saw an out-of-range activation
+    float *tw32 = nullptr, *tb32 = nullptr;     // f16x3: the tower in exact-f32 operand format as well (fallback launch)
     float *hw = nullptr, *hb = nullptr;         // head conv1x1: [2*hc][C], [2*hc]
     float *w0p = nullptr;                       // f16x3: conv0 as a K=32 GEMM on im2col rows, fragments [ct][hi|lo][lane][8 halves]
     float osc0 = 1.0f;                          // f16x3: 2^-sw0
@@ -213,7 +215,7 @@ __device__ __forceinline__ void wpre_load(WPre &pre, const f32x4 *wpk_layer, int
 template <int C, int NTT>
 __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
                                             const float *__restrict__ bias, float oscale, const int *vm, int rowbase,
-                                            int zbase, int W, int R, int wave, int lane, int residual, int *overflow, int tbase,
+                                            int zbase, int W, int R, int wave, int lane, int residual, bool &ovf_out, int tbase,
                                             const float *post_s, const float *post_t, WPre &pre, const f32x4 *next_wpk,
                                             unsigned long long *stamps = nullptr)
 {
@@ -363,7 +365,7 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
         if (stamps) { stamps[0] += t1 - t0; stamps[1] += t2 - t1; stamps[2] += t3 - t2; }
 #endif
     }
-    if (ovf) atomicOr(overflow, 1);
+    ovf_out |= ovf;
 }
 
 // ------------------------------------------------------------------------------------
@@ -419,7 +421,9 @@ struct TowerArgs {
     const float *w0p;        // f16x3: packed (hi, lo) fragments of w0 over k = tap*3 + c, padded to 32 (nullptr: VALU conv0)
     float osc0;
     float *hact;             // out: [sample][2*hc*HW]
-    int *overflow;
+    int *overflow;           // [0] sticky "an activation left f16's range", [1] samples re-evaluated in f32
+    int *ovf_flags;          // per sample: its f16x3 workgroup overflowed (set by PREC 1, consumed by the fallback launch)
+    int fallback;            // PREC 0 launch behind a PREC 1 one: only workgroups holding a flagged sample run
     int S, nblocks, hc;
     // tail handling (see nn_forward): role 0 = main launch, 1 / 2 = tail launches with fewer samples per workgroup
     int role, S_main, S_small, S_mid, S_big, cus;
@@ -458,6 +462,24 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     if (s0 >= limit) return;
     const int HW = g.HW, W = g.W, H = g.H;
     const int ns = min(S, limit - s0);
+    if constexpr (PREC == 0) {
+        // f16x3 safety net: this exact-f32 launch follows the f16x3 launches of the same batch and redoes the samples
+        // whose workgroup saw an activation beyond f16's range (none, normally: the workgroup leaves at once)
+        if (a.fallback) {
+            __shared__ int redo;
+            if (threadIdx.x == 0) {
+                int any = 0;
+                for (int i = 0; i < ns; i++) any |= a.ovf_flags[s0 + i];
+                redo = any;
+            }
+            __syncthreads();
+            if (!redo) return;
+            if (threadIdx.x == 0) {
+                for (int i = 0; i < ns; i++) a.ovf_flags[s0 + i] = 0;
+                atomicAdd(a.overflow + 1, ns);
+            }
+        }
+    }
     const int R = ns * HW;           // valid rows in this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NTHR = blockDim.x;
     // Zero REGION (3 rows, starting at a multiple of 16 float4 units) behind the S*HW rows of each
@@ -656,8 +678,8 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
             const f32x4 *src = (l & 1) ? Y4 : X4;
             f32x4 *dst = (l & 1) ? X4 : Y4;
             const f32x4 *nxt = l + 1 < NL ? tw4 + (size_t)(l + 1) * wl : nullptr;
-            if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase, nullptr, nullptr, pre, nxt, stamps);
-            else if constexpr (NTB > 0) conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, a.overflow, tbase, nullptr, nullptr, pre, nxt, stamps);
+            if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
+            else if constexpr (NTB > 0) conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
             STAMP(tb0);
             __syncthreads();
             STAMP(tb1);
@@ -753,7 +775,11 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         float *o = a.hact + (size_t)s0 * OC * HW;
         for (int i = tid; i < ns * OC * HW; i += NTHR) o[i] = stage[i];
     }
-    if (PREC == 1 && ovf) atomicOr(a.overflow, 1);
+    if (PREC == 1 && ovf) {
+        // (every thread that saw it says so; the stores are idempotent)
+        for (int i = 0; i < ns; i++) a.ovf_flags[s0 + i] = 1;
+        atomicOr(a.overflow, 1);
+    }
 #ifdef DBAZ_STAMP
     STAMP(tE1);
     if (PREC == 1 && a.stamp_out && lane == 0) {
@@ -880,7 +906,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_simple_trunk(Geo g, SimpleA
             WPre pre;
             wpre_load<C>(pre, tw4 + (size_t)l * wl16, wave, lane);
             conv_lds_h3<C, NTH>(src, dst, tw4 + (size_t)l * wl16, a.tb + l * C, a.tosc[l], vm, rowbase, zu, W, R, wave, lane, 0,
-                                a.overflow, tbase, a.ts + l * C, a.tt + l * C, pre, nullptr);
+                                ovf, tbase, a.ts + l * C, a.tt + l * C, pre, nullptr);
         }
         __syncthreads();
     }
@@ -1192,7 +1218,8 @@ static bool bn_affine(NNState *nn, const std::string &p, int n, std::vector<doub
 
 // conv3x3 [C][C][3][3] + following BN -> packed fragment order [C/16][9][C/16][64][4]
 static bool pack_conv(NNState *nn, const std::string &conv, const std::string &bn, int C, std::vector<float> &pk_all,
-                      std::vector<float> &bias_all, std::string &err, bool fold = true)
+                      std::vector<float> &bias_all, std::string &err, bool fold = true, std::vector<float> *pk32_all = nullptr,
+                      std::vector<float> *bias32_all = nullptr)
 {
     const int Cr = nn->Craw;
     auto w = sd_get(nn, conv + ".weight", (size_t)Cr * Cr * 9, err); if (!w) return false;
@@ -1217,6 +1244,8 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
                         pk[((((size_t)ct * 9 + tap) * KC + kc) * 64 + lane) * 4 + e] = (float)v;
                     }
     for (int co = 0; co < Cr; co++) bias[co] = (float)((double)(*b)[co] * s[co] + t[co]);
+    if (pk32_all) pk32_all->insert(pk32_all->end(), pk.begin(), pk.end());
+    if (bias32_all) bias32_all->insert(bias32_all->end(), bias.begin(), bias.end());
     if (nn->precision == 1) {
         // f16x3: folded weights scaled by 2^sw so that max|w| lands in [2^13, 2^14), split into
         // (hi, lo) halves, packed [ct][tap][ks][hi|lo][lane][8]; bias carries the activation scale
@@ -1259,10 +1288,10 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
 
 // launches (or, with attr_only, raises the dynamic-LDS limit of) the instantiation for (C, NTT, PREC)
 template <int C, int NTA, int NTB>
-static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, int grid, bool attr_only)
+static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, int grid, bool attr_only, int prec)
 {
     if constexpr (C >= 32) {
-        if (nn->precision == 1) {
+        if (prec == 1) {
             if (attr_only)
                 return hipFuncSetAttribute((const void *)k_tower<C, NTA, NTB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
             hipLaunchKernelGGL((k_tower<C, NTA, NTB, 1>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
@@ -1275,23 +1304,24 @@ static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, in
     return hipSuccess;
 }
 template <int C>
-static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, int ntt, int grid, bool attr_only)
+static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, int ntt, int grid, bool attr_only, int prec)
 {
     switch (ntt) {
-    case 2: return tower_inst<C, 2, 2>(nn, s, ta, grid, attr_only);
-    case 4: return tower_inst<C, 4, 4>(nn, s, ta, grid, attr_only);
-    case 5: return tower_inst<C, 5, 5>(nn, s, ta, grid, attr_only);
-    default: return tower_inst<C, 7, 6>(nn, s, ta, grid, attr_only);
+    case 2: return tower_inst<C, 2, 2>(nn, s, ta, grid, attr_only, prec);
+    case 4: return tower_inst<C, 4, 4>(nn, s, ta, grid, attr_only, prec);
+    case 5: return tower_inst<C, 5, 5>(nn, s, ta, grid, attr_only, prec);
+    default: return tower_inst<C, 7, 6>(nn, s, ta, grid, attr_only, prec);
     }
 }
-// ntt: tiles per wave of the instantiation (7 -> <7,6>, 5 -> <5,5>, 4 -> <4,4>, 2 -> <2,2>)
-static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const TowerArgs &ta, int ntt, int grid, bool attr_only)
+// ntt: tiles per wave of the instantiation (7 -> <7,6>, 5 -> <5,5>, 4 -> <4,4>, 2 -> <2,2>); prec < 0: the handle's
+static hipError_t tower_dispatch(NNState *nn, hipStream_t s, const TowerArgs &ta, int ntt, int grid, bool attr_only, int prec = -1)
 {
+    if (prec < 0) prec = nn->precision;
     switch (nn->C) {
-    case 16: return tower_inst_c<16>(nn, s, ta, ntt, grid, attr_only);
-    case 32: return tower_inst_c<32>(nn, s, ta, ntt, grid, attr_only);
-    case 64: return tower_inst_c<64>(nn, s, ta, ntt, grid, attr_only);
-    default: return tower_inst_c<128>(nn, s, ta, ntt, grid, attr_only);
+    case 16: return tower_inst_c<16>(nn, s, ta, ntt, grid, attr_only, prec);
+    case 32: return tower_inst_c<32>(nn, s, ta, ntt, grid, attr_only, prec);
+    case 64: return tower_inst_c<64>(nn, s, ta, ntt, grid, attr_only, prec);
+    default: return tower_inst_c<128>(nn, s, ta, ntt, grid, attr_only, prec);
     }
 }
 
@@ -1488,15 +1518,25 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         }
     }
     {
-        std::vector<float> pk_all, bias_all;
+        std::vector<float> pk_all, bias_all, pk32_all, bias32_all;
+        const bool both = nn->precision == 1 && C >= 32; // f16x3 handles keep the exact-f32 operands too (safety net)
         nn->osc_host.clear();
         for (int i = 0; i < nn->blocks; i++) {
             std::string p = "resnet.resblocks." + std::to_string(i);
-            if (!pack_conv(nn, p + ".conv1", p + ".bn1", C, pk_all, bias_all, err)) return DBAZ_EINVAL;
-            if (!pack_conv(nn, p + ".conv2", p + ".bn2", C, pk_all, bias_all, err)) return DBAZ_EINVAL;
+            if (!pack_conv(nn, p + ".conv1", p + ".bn1", C, pk_all, bias_all, err, true, both ? &pk32_all : nullptr, both ? &bias32_all : nullptr)) return DBAZ_EINVAL;
+            if (!pack_conv(nn, p + ".conv2", p + ".bn2", C, pk_all, bias_all, err, true, both ? &pk32_all : nullptr, both ? &bias32_all : nullptr)) return DBAZ_EINVAL;
         }
         nn->tw = nn_upload(nn, pk_all);
         nn->tb = nn_upload(nn, bias_all);
+        nn->tw32 = nn->tb32 = nullptr;
+        nn->ovf_flags = nullptr;
+        if (both) {
+            nn->tw32 = nn_upload(nn, pk32_all);
+            nn->tb32 = nn_upload(nn, bias32_all);
+            nn->ovf_flags = nn_alloc<int>(nn, (size_t)nn->max_batch + 16);
+            if (!nn->tw32 || !nn->tb32 || !nn->ovf_flags) { err = "hipMalloc failed (f32 fallback weights)"; return DBAZ_EDEVICE; }
+            (void)hipMemset(nn->ovf_flags, 0, ((size_t)nn->max_batch + 16) * sizeof(int));
+        }
         if (nn->osc_host.empty()) nn->osc_host.push_back(1.0f);
         nn->tosc = nn_upload(nn, nn->osc_host);
         nn->overflow = nn_alloc<int>(nn, 4);
@@ -1632,6 +1672,7 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
             nn->cus = cus;
     }
     hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true);
+    if (he == hipSuccess && nn->tw32) he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true, 0);
     if (he == hipSuccess && nn->S_mid > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 4, 0, true);
     if (he == hipSuccess && nn->S_small > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 2, 0, true);
     if (he == hipSuccess && nn->S_big > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 5, 0, true);
@@ -1674,7 +1715,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     TowerArgs ta;
     ta.feat = feat; ta.list = list_dev; ta.n_dev = n_dev; ta.in_s = nn->in_s; ta.in_t = nn->in_t; ta.w0 = nn->w0; ta.b0 = nn->b0;
     ta.tw = nn->tw; ta.tb = nn->tb; ta.tosc = nn->tosc; ta.hw = nn->hw; ta.hb = nn->hb; ta.hwp = nn->hwp; ta.hosc = nn->hosc; ta.w0p = nn->w0p; ta.osc0 = nn->osc0; ta.hact = nn->hact;
-    ta.overflow = nn->overflow; ta.S = nn->S; ta.nblocks = nn->blocks; ta.hc = hc;
+    ta.overflow = nn->overflow; ta.ovf_flags = nn->ovf_flags; ta.fallback = 0; ta.S = nn->S; ta.nblocks = nn->blocks; ta.hc = hc;
     ta.stamp_out = nn->stamp_out;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.S_big = nn->S_big; ta.cus = nn->cus;
@@ -1691,6 +1732,13 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     if (nn->S_big > 0) {   // tail <= cus * S_big samples: one round of <5,5> workgroups
         ta.role = 3; ta.S = nn->S_big;
         (void)tower_dispatch(nn, s, ta, 5, nn->cus, false);
+    }
+    if (nn->precision == 1 && nn->tw32) {
+        // safety net of the f16x3 mode: samples whose workgroup saw an activation leave f16's range are redone by the
+        // exact-f32 tower (its workgroups check the per-sample flags on the device and leave at once otherwise)
+        ta.role = 0; ta.S = nn->S; ta.S_small = ta.S_mid = ta.S_big = 0; ta.fallback = 1;
+        ta.tw = nn->tw32; ta.tb = nn->tb32; ta.w0p = nullptr; ta.hwp = nullptr;
+        (void)tower_dispatch(nn, s, ta, nn->NTT, (max_n + nn->S - 1) / nn->S, false, 0);
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
     HeadArgs ha;
@@ -1721,10 +1769,21 @@ int nn_read_stamps(NNState *nn, unsigned long long *out, int n_wg)
     return (int)hipMemcpy(out, nn->stamp_out, (size_t)n_wg * 8 * 10 * 8, hipMemcpyDeviceToHost);
 }
 
+// f16x3 mode, networks WITHOUT the exact-f32 safety net (SimpleNN; ResNetZero narrower than 32 channels never runs
+// f16x3): non-zero once an activation exceeded f16's range (results invalid: use precision 0)
 int nn_overflowed(NNState *nn)
 {
-    if (!nn || !nn->overflow) return 0;
+    if (!nn || !nn->overflow || nn->tw32) return 0;
     int v = 0;
     (void)hipMemcpy(&v, nn->overflow, 4, hipMemcpyDeviceToHost);
     return v;
+}
+
+// f16x3 mode with the safety net: samples re-evaluated by the exact-f32 tower so far
+long long nn_fallback_evals(NNState *nn)
+{
+    if (!nn || !nn->overflow || !nn->tw32) return 0;
+    int v[2] = {0, 0};
+    (void)hipMemcpy(v, nn->overflow, 8, hipMemcpyDeviceToHost);
+    return v[1];
 }

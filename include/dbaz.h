@@ -66,7 +66,8 @@ typedef struct {
     int32_t device;         /* HIP device ordinal */
     uint64_t seed;          /* Philox key for move sampling / Dirichlet noise */
     int32_t max_out_rows;   /* capacity of the finished-sample buffer; 0 = max(4096, 2*n_slots*(E+1)) */
-    int32_t nn_precision;   /* 0 = exact f32 MFMA; 1 = f16x3 split MFMA (f32-grade) */
+    int32_t nn_precision;   /* 0 = exact f32 MFMA; 1 = f16x3 split MFMA (f32-grade; an evaluation whose activations leave
+                             * f16's range is redone in exact f32 on the device, counters.f32_fallback_evals) */
     int32_t match_play;     /* two-model match play (self_play.compute_elo, :309-344): the evaluator of a move's
                                search is model (root.to_play XOR game_idx&1) */
     int32_t evaluator2;     /* DBAZ_EVAL_* of model 1 (match play) */
@@ -89,7 +90,8 @@ typedef struct {
     int32_t active_slots;   /* slots still playing */
     int32_t error_slots;    /* slots stopped by an error (pool exhausted) */
     int32_t blocked_slots;  /* finished games waiting for room in the output buffer: fetch samples */
-    int32_t reserved;
+    int32_t f32_fallback_evals; /* nn_precision = 1, ResNetZero: leaves whose f16x3 evaluation left f16's range and were
+                                 * re-evaluated by the exact-f32 tower in the same step (normally 0) */
     /* HIP-event timing of the last timed region (dbaz_timing_begin/_end) */
     double ms_total, ms_tree, ms_nn;
     int64_t nn_launches;    /* conv-tower launches inside the timed region */

@@ -130,14 +130,77 @@ def test_f16x3_split_precision_mode(rows, cols, ch, nb, n):
     e0.close()
 
 
-def test_f16x3_reports_range_overflow():
-    """Activations beyond f16's range must not silently produce garbage."""
+def _scaled_block_net(K):
+    """ResNetZero whose FUNCTION is that of an ordinary random-init net, but whose activations between conv1 and
+    conv2 of block 1 are K times larger (bn1 scaled by K, conv2's weights by 1/K; ReLU is positively homogeneous)."""
+    torch.manual_seed(4)
+    m = nn_ref.ResNetZeroRef(6, 6, 64, 3)
+    nn_ref.randomize_bn(m, 2)
+    with torch.no_grad():
+        blk = m.resnet.resblocks[1]
+        blk.bn1.weight.mul_(K)
+        blk.bn1.bias.mul_(K)
+        blk.conv2.weight.div_(K)
+    return m
+
+
+def test_f16x3_range_overflow_falls_back_to_exact_f32():
+    """f16x3 safety net: activations beyond f16's range (here ~4096 x the usual ones inside one block) must not
+    produce garbage or stop play -- the affected evaluations are redone by the exact-f32 tower on the device, in the
+    same step, and (p, v) stay within the 1e-4 tolerance of the torch fp32 restatement."""
+    m = _scaled_block_net(4096.0)
+    e = engine_for(6, 6, m, n_slots=64, precision=1)
+    rng = np.random.RandomState(3)
+    X = rng.randint(0, 2, size=(37, 3, 7, 7)).astype(np.float32)
+    X[:, 2] = rng.randint(0, 37, size=(37, 1, 1))
+    p, v = e.predict(X)
+    pr, vr = nn_ref.predict_sync(m, X)
+    assert np.isfinite(p).all() and np.abs(p - pr).max() < TOL and np.abs(v - vr).max() < TOL
+    c = e.counters()
+    assert 37 <= c["f32_fallback_evals"] <= 40  # every sample (in whole workgroups of 4)
+    e.close()
+    # play continues: complete self-play games with this network, fallbacks counted, no error
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(6, 6, 8, mcts_num_read=12, noise=(0.8, 0.25), evaluator="resnet", nn_precision=1, seed=2)
+    e.load_state_dict(m.state_dict(), "resnet", 64, 3, 16, 8)
+    e.selfplay_start(8, 0)
+    e.run()
+    c = e.counters()
+    assert c["games_finished"] == 8 and c["error_slots"] == 0 and c["f32_fallback_evals"] >= c["nn_evals"] > 0
+    e.close()
+
+
+def test_f16x3_fallback_only_touches_the_overflowing_samples():
+    """Inputs are what overflows here (two samples with a huge plane-2 value): only their workgroups are redone in
+    f32; an ordinary network, every output within tolerance, ordinary batches afterwards cost no fallback."""
+    torch.manual_seed(9)
+    m = nn_ref.ResNetZeroRef(6, 6, 64, 3)
+    nn_ref.randomize_bn(m, 2)
+    e = engine_for(6, 6, m, n_slots=2048, precision=1)
+    rng = np.random.RandomState(5)
+    n = 1500  # > 1024: the main launch (4 samples per workgroup) and a tail launch both run
+    X = rng.randint(0, 2, size=(n, 3, 7, 7)).astype(np.float32)
+    X[:, 2] = rng.randint(0, 37, size=(n, 1, 1))
+    X[5, 2] = 40000.0
+    X[1444, 2] = -35000.0
+    p, v = e.predict(X)
+    pr, vr = nn_ref.predict_sync(m, X)
+    assert np.abs(p - pr).max() < TOL and np.abs(v - vr).max() < TOL
+    c = e.counters()
+    assert 2 <= c["f32_fallback_evals"] <= 8
+    e.predict(X[100:400])
+    assert e.counters()["f32_fallback_evals"] == c["f32_fallback_evals"]
+    e.close()
+
+
+def test_f16x3_simplenn_still_reports_range_overflow():
+    """SimpleNN has no f32 safety net: out-of-range activations remain a loud error."""
     from dotsboxesaz_amd import _lib
     torch.manual_seed(0)
-    m = nn_ref.ResNetZeroRef(3, 3, 32, 2)
+    m = nn_ref.SimpleNNRef()
     with torch.no_grad():
-        m.resnet.conv0.weight.mul_(1e5)
-    e = engine_for(3, 3, m, n_slots=8, precision=1)
+        m.conv0.weight.mul_(1e5)
+    e = simple_engine(m, 1, n_slots=8)
     with pytest.raises(_lib.DbazError):
         e.predict(np.ones((2, 3, 4, 4), np.float32))
     e.close()
