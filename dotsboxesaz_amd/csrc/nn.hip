@@ -430,56 +430,13 @@ struct TowerArgs {
     unsigned long long *stamp_out; // diagnostic build only
 };
 
+// the S samples [s0, s0 + ns) of one workgroup through the whole trunk
 template <int C, int NTA, int NTB, int PREC>
-__global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
+__device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, float *lds, const int S, const int s0, const int ns)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int STRIDE = C + 8;
     constexpr int S4 = STRIDE / 4;
-    const int n = *a.n_dev;
-    const int S = a.S;
-    // Every workgroup of a launch takes the same time, so the launch costs ceil(workgroups / CUs) rounds and a
-    // nearly empty last round costs a full one.  The samples beyond the last FULL round of the main launch are
-    // therefore left to a tail launch with fewer samples (and position tiles) per workgroup whenever one round of
-    // those smaller, faster workgroups can take them; every launch derives the split from n on the device.
-    int first_sample = 0, limit = n;
-    {
-        const int per_round = a.cus * a.S_main;
-        const int n_full = per_round > 0 ? (n / per_round) * per_round : 0;
-        const int tail = n - n_full;
-        int mode = 0;
-        if (tail > 0 && a.S_small > 0 && tail <= a.cus * a.S_small) mode = 1;
-        else if (tail > 0 && a.S_mid > 0 && tail <= a.cus * a.S_mid) mode = 2;
-        else if (tail > 0 && a.S_big > 0 && tail <= a.cus * a.S_big) mode = 3;
-        if (a.role == 0) {
-            if (mode) limit = n_full;
-        } else {
-            if (mode != a.role) return;
-            first_sample = n_full;
-        }
-    }
-    const int s0 = first_sample + blockIdx.x * S;
-    if (s0 >= limit) return;
     const int HW = g.HW, W = g.W, H = g.H;
-    const int ns = min(S, limit - s0);
-    if constexpr (PREC == 0) {
-        // f16x3 safety net: this exact-f32 launch follows the f16x3 launches of the same batch and redoes the samples
-        // whose workgroup saw an activation beyond f16's range (none, normally: the workgroup leaves at once)
-        if (a.fallback) {
-            __shared__ int redo;
-            if (threadIdx.x == 0) {
-                int any = 0;
-                for (int i = 0; i < ns; i++) any |= a.ovf_flags[s0 + i];
-                redo = any;
-            }
-            __syncthreads();
-            if (!redo) return;
-            if (threadIdx.x == 0) {
-                for (int i = 0; i < ns; i++) a.ovf_flags[s0 + i] = 0;
-                atomicAdd(a.overflow + 1, ns);
-            }
-        }
-    }
     const int R = ns * HW;           // valid rows in this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NTHR = blockDim.x;
     // Zero REGION (3 rows, starting at a multiple of 16 float4 units) behind the S*HW rows of each
@@ -790,6 +747,71 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         o[8] = __builtin_amdgcn_s_memrealtime() - tR0; // the same interval in 100 MHz ticks: clock = o[7] / o[8] * 100 MHz
     }
 #endif
+}
+
+template <int C, int NTA, int NTB, int PREC>
+__global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n = *a.n_dev;
+    const int S = a.S;
+    // Every workgroup of a launch takes the same time, so the launch costs ceil(workgroups / CUs) rounds and a
+    // nearly empty last round costs a full one.  The samples beyond the last FULL round of the main launch are
+    // therefore left to a tail launch with fewer samples (and position tiles) per workgroup whenever one round of
+    // those smaller, faster workgroups can take them; every launch derives the split from n on the device.
+    int first_sample = 0, limit = n;
+    {
+        const int per_round = a.cus * a.S_main;
+        const int n_full = per_round > 0 ? (n / per_round) * per_round : 0;
+        const int tail = n - n_full;
+        int mode = 0;
+        if (tail > 0 && a.S_small > 0 && tail <= a.cus * a.S_small) mode = 1;
+        else if (tail > 0 && a.S_mid > 0 && tail <= a.cus * a.S_mid) mode = 2;
+        else if (tail > 0 && a.S_big > 0 && tail <= a.cus * a.S_big) mode = 3;
+        if (a.role == 0) {
+            if (mode) limit = n_full;
+        } else {
+            if (mode != a.role) return;
+            first_sample = n_full;
+        }
+    }
+    if constexpr (PREC == 0) {
+        if (a.fallback) {
+            // f16x3 safety net: this exact-f32 launch follows the f16x3 launches of the same batch and redoes the sample
+            // groups in which a workgroup saw an activation beyond f16's range (none, normally).  It is ONE round of
+            // workgroups; thread t of workgroup b looks at group b + t * gridDim.x, the flagged ones are then redone one
+            // after the other (a full grid of idle 114-KB-LDS workgroups cost 17 us per step just to be dispatched).
+            __shared__ int n_redo;
+            __shared__ int redo_grp[CONV_THREADS];
+            if (threadIdx.x == 0) n_redo = 0;
+            __syncthreads();
+            {
+                const int gt = blockIdx.x + threadIdx.x * gridDim.x;
+                const long long st = (long long)gt * S;
+                if (st < n) {
+                    int any = 0;
+                    const int m = min(S, n - (int)st);
+                    for (int i = 0; i < m; i++) any |= a.ovf_flags[st + i];
+                    if (any) {
+                        for (int i = 0; i < m; i++) a.ovf_flags[st + i] = 0;
+                        redo_grp[atomicAdd(&n_redo, 1)] = gt;
+                        atomicAdd(a.overflow + 1, m);
+                    }
+                }
+            }
+            __syncthreads();
+            const int nr = n_redo;
+            for (int r = 0; r < nr; r++) {
+                const int s0 = redo_grp[r] * S;
+                tower_group<C, NTA, NTB, PREC>(g, a, lds, S, s0, min(S, n - s0));
+                __syncthreads();
+            }
+            return;
+        }
+    }
+    const int s0 = first_sample + blockIdx.x * S;
+    if (s0 >= limit) return;
+    tower_group<C, NTA, NTB, PREC>(g, a, lds, S, s0, min(S, limit - s0));
 }
 
 // ------------------------------------------------------------------------------------
@@ -1733,12 +1755,13 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
         ta.role = 3; ta.S = nn->S_big;
         (void)tower_dispatch(nn, s, ta, 5, nn->cus, false);
     }
-    if (nn->precision == 1 && nn->tw32) {
+    static const bool no_fb = getenv("DBAZ_NO_FALLBACK") != nullptr; // measurement aid only
+    if (nn->precision == 1 && nn->tw32 && !no_fb) {
         // safety net of the f16x3 mode: samples whose workgroup saw an activation leave f16's range are redone by the
         // exact-f32 tower (its workgroups check the per-sample flags on the device and leave at once otherwise)
         ta.role = 0; ta.S = nn->S; ta.S_small = ta.S_mid = ta.S_big = 0; ta.fallback = 1;
         ta.tw = nn->tw32; ta.tb = nn->tb32; ta.w0p = nullptr; ta.hwp = nullptr;
-        (void)tower_dispatch(nn, s, ta, nn->NTT, (max_n + nn->S - 1) / nn->S, false, 0);
+        (void)tower_dispatch(nn, s, ta, nn->NTT, std::min((max_n + nn->S - 1) / nn->S, nn->cus), false, 0);
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
     HeadArgs ha;
