@@ -115,7 +115,7 @@ def make_engine(args, precision, rank, local_rank, torch, slots=None):
     rows = cols = args.board
     eng = Engine(rows, cols, slots or args.slots, mcts_num_read=args.sims, noise=(0.8, 0.25), reuse_tree=True,
                  evaluator=args.evaluator, seed=1000 + rank, device=local_rank, nn_precision=precision,
-                 nodes_per_slot=args.nodes_per_slot)
+                 nodes_per_slot=args.nodes_per_slot, transposition_cache=not args.no_tt)
     if args.evaluator == "resnet":
         torch.manual_seed(0)
         model = dnn.ResNetZero(dnn.resnet_params(rows, cols, args.channels, args.blocks))
@@ -303,7 +303,8 @@ def tower_roofline(args, m, steps, precision):
     ach = m["nn_evals"] * conv_flops * 2 * args.blocks / (m["ms_nn_tower"] * 1e-3) / 1e12
     peak = F32_MFMA_PEAK_TFLOPS if precision == 0 else F16_MFMA_PEAK_TFLOPS / 3.0
     return {"bound": "mfma",
-            "kernel": "k_tower<%d,*,%d> (conv0 + 2*%d conv3x3 + head 1x1 convs fused, LDS-resident)" % (args.channels, precision, args.blocks),
+            "kernel": "k_tower<%d,*,%s> (conv0 + 2*%d conv3x3 + head 1x1 convs fused, LDS-resident)"
+                      % (args.channels, {0: "f32", 1: "f16x3 on 16x16x32", 2: "f16x3 on 32x32x16"}[precision], args.blocks),
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "peak_note": ("dense f32 MFMA" if precision == 0 else
                           "dense f16 MFMA / 3 (three f16 MFMAs per f32-grade product); algorithmic flops counted once"),
@@ -324,12 +325,14 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "simplenn", "formula", "uniform"])
-    ap.add_argument("--precision", type=int, default=1,
-                    help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default)")
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2],
+                    help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default); 2 = the same arithmetic on "
+                         "the 32x32x16 MFMA tiling (DESIGN.md 5.1: measured, not faster)")
     ap.add_argument("--nodes-per-slot", type=int, default=0, help="tree node pool per game (0 = engine default 10*(sims+2))")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-side-run", action="store_true")
+    ap.add_argument("--no-tt", action="store_true", help="switch the per-game transposition table off (kernel measurements)")
     ap.add_argument("--fresh-population", action="store_true",
                     help="skip the population preparation (staggered first searches + sims+64 untimed steps): every tree "
                          "starts empty, as in round 1's bench")
@@ -375,7 +378,7 @@ def main():
         gather = dict(rows=rows_total, ms=ms)
     eng.close()
     side = None
-    if args.evaluator == "resnet" and args.precision == 1 and not args.no_f32_side_run:
+    if args.evaluator == "resnet" and args.precision >= 1 and not args.no_f32_side_run:
         st = max(20, args.steps // 6)
         eng0, m0 = run_engine(args, 0, st, max(5, args.warmup // 5), rank, local_rank, world, dist, torch)
         eng0.close()

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdbaz_hip.so")
+LIB_PATH = os.environ.get("DBAZ_LIB") or os.path.join(_HERE, "libdbaz_hip.so")  # DBAZ_LIB: diagnostic builds (tools/)
 
 OK, EINVAL, EILLEGAL, EDEVICE, EPOOL, ESTATE = range(6)
 RESULT_NONE = 2

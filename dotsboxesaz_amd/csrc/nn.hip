@@ -41,7 +41,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CONV_THREADS 512 // 8 waves: two per SIMD, wave = (cout tile, half of the position tiles)
-#define MAXT 13 // position tiles (16 rows each) per workgroup
+#define MAXT 13 // position tiles (16 rows each) per workgroup (16x16x32 tiling); the 32x32x16 tiling holds 8 tiles of 32 rows
+#define MAXROWS 256
 
 struct NNState {
     Geo g;
@@ -79,6 +80,10 @@ struct NNState {
     int S = 1, NT = 1, NTT = 7;                 // samples / position tiles per conv workgroup (NTT: compiled tile count)
     int S_small = 0, S_mid = 0, S_big = 0, cus = 256; // tail launches: samples per workgroup of the <2,2> / <4,4> / <5,5> variants (0: unused)
     size_t conv_lds = 0;
+    // f16x3 on the 32x32x16 tiling (k_tower<..., MF = 1>): its own workgroup geometry; S / NTT / conv_lds above then describe the
+    // 16x16 kernels, which remain in use for the exact-f32 fallback launch
+    int want_mf32 = 0, mf32 = 0, S_mf = 0, NT2 = 0, S_mf_tail = 0;
+    size_t conv_lds_mf = 0;
 };
 
 // ------------------------------------------------------------------------------------
@@ -369,6 +374,175 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
 }
 
 // ------------------------------------------------------------------------------------
+// The same f16x3 layer on v_mfma_f32_32x32x16_f16 (MF = 1).  Output tile = 32 couts x 32 positions: a wave owns one
+// 32-cout tile (wave & 1) and NTT position tiles of 32 rows (tile group wave >> 1); per K=16 step it needs ONE weight
+// fragment pair for 3 * NTT MFMAs of 32 cycles each, and every activation fragment feeds twice the MACs of the 16x16x32
+// tiling -- half the LDS read bytes and half the vector-issue slots per FLOP (the 16x16x32 form holds the issue port
+// for 8 of its 16 cycles, this one for 8 of 32).  LDS rows are [C hi | C lo | 16 B pad] = C + 4 dwords: with 17 units
+// of 16 B per row the 32 rows of a fragment fall on distinct bank slots inside every 16-lane group of ds_read_b128.
+// Lane map (cdna_hip_programming.md 3): lane l, r = l & 31, h = l >> 5: A[cout r][k = 8h + j], B[k = 8h + j][pos r];
+// D: pos = l & 31, cout = (reg & 3) + 8 (reg >> 2) + 4 h.
+// ------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int C>
+__device__ __forceinline__ void wpre_load32(WPre &pre, const f32x4 *wpk_layer, int wave, int lane)
+{
+    constexpr int N = 9 * (C / 16);
+    const f32x4 *wb = wpk_layer + (size_t)(wave & 1) * N * 2 * 64 + lane;
+    pre.h0 = wb[0];
+    pre.l0 = wb[64];
+    pre.h1 = wb[128];
+    pre.l1 = wb[192];
+}
+
+template <int C, int NTT>
+__device__ __forceinline__ void conv_lds_h3_32(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
+                                               const float *__restrict__ bias, float oscale, const int *vm, int rowbase,
+                                               int zbase, int W, int R, int wave, int lane, int residual, bool &ovf_out, int tbase,
+                                               WPre &pre, const f32x4 *next_wpk, unsigned long long *stamps = nullptr)
+{
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)stamps;
+    constexpr int S4 = (C + 4) / 4;  // 16-byte units per LDS row
+    constexpr int KS = C / 16;       // K=16 steps per tap
+    constexpr int LO = C / 8;        // unit offset of the lo halves inside a row
+    constexpr int N = 9 * KS;        // pipeline steps per cout tile
+    const int jrow = lane & 31, gq = lane >> 5;
+    bool ovf = false;
+    for (int ct = wave & 1; ct < C / 32; ct += 2) {
+        f32x16 acc[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+        const f32x4 *wbase = wpk + (size_t)ct * N * 2 * 64 + lane; // packed [ct][step][hi|lo][lane] 16-byte fragments
+        u128h a_h[3], a_l[3];
+        u128h bh[NTT], bl[NTT];
+        const char *sb = reinterpret_cast<const char *>(src4);
+        int ab[NTT]; // BYTE address of this lane's fragment for the current tap (tile constant folded out)
+#pragma unroll
+        for (int t = 0; t < NTT; t++)
+            ab[t] = ((vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 32 * S4) * 16;
+        STAMP(t0);
+        if (ct == (wave & 1)) { // first cout tile of the layer: fragments were prefetched across the barrier
+            a_h[0].f = pre.h0; a_l[0].f = pre.l0; a_h[1].f = pre.h1; a_l[1].f = pre.l1;
+        } else {
+            a_h[0].f = wbase[0];
+            a_l[0].f = wbase[64];
+            a_h[1].f = wbase[128];
+            a_l[1].f = wbase[192];
+        }
+#pragma unroll
+        for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 512 * S4);
+#pragma unroll
+        for (int t = 0; t < NTT; t++) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 512 * S4 + LO * 16);
+        STAMP(t1);
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const int cur = i % 3, nxt = (i + 2) % 3;
+            const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
+            if (i + 2 < N) {
+                a_h[nxt].f = wbase[(size_t)(i + 2) * 128];
+                a_l[nxt].f = wbase[(size_t)(i + 2) * 128 + 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // G1: hi*hi (the next tap's addresses are computed in its shadow)
+#pragma unroll
+            for (int t = 0; t < NTT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[cur].h, bh[t].h, acc[t], 0, 0, 0);
+            if (ni < N && nks == 0) {
+                const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
+                const int zt = zbase + ((rowbase + off) & 15);
+#pragma unroll
+                for (int t = 0; t < NTT; t++) ab[t] = (((vm[t] >> ntap) & 1) ? rowbase + off : zt - t * 32 * S4) * 16;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // G3: lo*hi; bh[t] is dead after its MFMA -> reload it for the next step right there
+#pragma unroll
+            for (int t = 0; t < NTT; t++) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[cur].h, bh[t].h, acc[t], 0, 0, 0);
+                if (ni < N) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 512 * S4 + nks * 32);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // G2: hi*lo; same for bl[t]
+#pragma unroll
+            for (int t = 0; t < NTT; t++) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[cur].h, bl[t].h, acc[t], 0, 0, 0);
+                if (ni < N) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 512 * S4 + nks * 32 + LO * 16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        STAMP(t2);
+        // bias before the cross-barrier weight prefetch (loads return in order)
+        f32x4 bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bv[q] = *reinterpret_cast<const f32x4 *>(bias + ct * 32 + 8 * q + 4 * gq);
+            asm volatile("" ::"v"(bv[q]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (next_wpk && ct + 2 >= C / 32) wpre_load32<C>(pre, next_wpk, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue: this lane holds, of position row (tbase + t) * 32 + jrow, the couts ct*32 + 8q + 4gq .. +3 (q = 0..3)
+        _Float16 *dsth = reinterpret_cast<_Float16 *>(dst4);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        u32x2 rh[NTT][4], rl[NTT][4];
+        if (residual) {
+#pragma unroll
+            for (int t = 0; t < NTT; t++) {
+                const int row = min((tbase + t) * 32 + jrow, R - 1);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const _Float16 *ph = dsth + (size_t)row * (S4 * 8) + ct * 32 + 8 * q + 4 * gq;
+                    rh[t][q] = *reinterpret_cast<const u32x2 *>(ph);
+                    rl[t][q] = *reinterpret_cast<const u32x2 *>(ph + C);
+                }
+            }
+        }
+        float vmax = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            const int row = (tbase + t) * 32 + jrow;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v = (f32x4){acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]} * oscale + bv[q];
+                if (residual) {
+                    union { unsigned int u; h2v h; } c0, c1, d0, d1;
+                    c0.u = rh[t][q][0]; c1.u = rh[t][q][1]; d0.u = rl[t][q][0]; d1.u = rl[t][q][1];
+                    v[0] += (float)c0.h[0] + (float)d0.h[0];
+                    v[1] += (float)c0.h[1] + (float)d0.h[1];
+                    v[2] += (float)c1.h[0] + (float)d1.h[0];
+                    v[3] += (float)c1.h[1] + (float)d1.h[1];
+                }
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                vmax = fmaxf(vmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+                union { h2v h[2]; u32x2 u; } oh, ol;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const f2v x = {v[2 * e], v[2 * e + 1]};
+                    const h2v h = __builtin_convertvector(x, h2v);
+                    oh.h[e] = h;
+                    ol.h[e] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
+                }
+                if (row < R) {
+                    _Float16 *ph = dsth + (size_t)row * (S4 * 8) + ct * 32 + 8 * q + 4 * gq;
+                    *reinterpret_cast<u32x2 *>(ph) = oh.u;
+                    *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
+                }
+            }
+        }
+        ovf |= vmax > F16_GUARD;
+        STAMP(t3);
+#ifdef DBAZ_STAMP
+        if (stamps) { stamps[0] += t1 - t0; stamps[1] += t2 - t1; stamps[2] += t3 - t2; }
+#endif
+    }
+    ovf_out |= ovf;
+}
+
+// ------------------------------------------------------------------------------------
 // The whole convolutional trunk in ONE launch per step.  A workgroup owns S samples; their
 // activations live in two ping-pong LDS images of (S*HW+1) rows x (C+8) dwords for
 //   conv0 (3 -> C, VALU, bn_input fused on load, BN0 folded, ReLU)
@@ -379,10 +553,9 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
 // from L2.  PREC 0: exact f32 (rows hold C floats); PREC 1: f16x3 (rows hold C hi + C lo halves
 // of the activation scaled by 2^ACT_SHIFT).
 // ------------------------------------------------------------------------------------
-template <int C, int PREC>
+template <int C, int PREC, int STRIDE = C + 8>
 __device__ __forceinline__ void act_store(float *lds, int row, int c, float v, bool &ovf)
 {
-    constexpr int STRIDE = C + 8;
     if constexpr (PREC == 0) {
         lds[row * STRIDE + c] = v;
     } else {
@@ -394,10 +567,9 @@ __device__ __forceinline__ void act_store(float *lds, int row, int c, float v, b
         h[C + c] = (_Float16)(x - (float)hi);
     }
 }
-template <int C, int PREC>
+template <int C, int PREC, int STRIDE = C + 8>
 __device__ __forceinline__ float act_load(const float *lds, int row, int c)
 {
-    constexpr int STRIDE = C + 8;
     if constexpr (PREC == 0) {
         return lds[row * STRIDE + c];
     } else {
@@ -431,10 +603,11 @@ struct TowerArgs {
 };
 
 // the S samples [s0, s0 + ns) of one workgroup through the whole trunk
-template <int C, int NTA, int NTB, int PREC>
+template <int C, int NTA, int NTB, int PREC, int MF>
 __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, float *lds, const int S, const int s0, const int ns)
 {
-    constexpr int STRIDE = C + 8;
+    static_assert(MF == 0 || PREC == 1, "the 32x32x16 tiling exists for the f16x3 mode only");
+    constexpr int STRIDE = MF ? C + 4 : C + 8; // dwords per LDS row (see conv_lds_h3_32 for the 32x32x16 tiling's choice)
     constexpr int S4 = STRIDE / 4;
     const int HW = g.HW, W = g.W, H = g.H;
     const int R = ns * HW;           // valid rows in this workgroup
@@ -464,7 +637,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         bool mfma0 = false; // the im2col image (10 units per row) must fit behind the padded planes in the idle image
         if constexpr (PREC == 1) mfma0 = a.w0p != nullptr && ((((S * PP + 3) / 4 + 1) & ~1) + S * HW * 10 <= img_units);
         __shared__ int slot_s[16];    // sample -> slot (S <= 13)
-        __shared__ int rowbase_s[16 * MAXT]; // position row -> offset of its 3x3 window in the padded planes
+        __shared__ int rowbase_s[MAXROWS]; // position row -> offset of its 3x3 window in the padded planes
         for (int i = tid; i < ns * PP; i += NTHR) pad[i] = 0.0f;
         if (tid < ns) slot_s[tid] = a.list ? a.list[s0 + tid] : s0 + tid;
         if (tid < R) {
@@ -580,7 +753,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
 #pragma unroll
                 for (int k = 0; k < 27; k++) acc += in27[k] * *reinterpret_cast<const f32x4 *>(wl + k * C + co);
 #pragma unroll
-                for (int e = 0; e < 4; e++) act_store<C, PREC>(X, row, co + e, fmaxf(acc[e], 0.0f), ovf);
+                for (int e = 0; e < 4; e++) act_store<C, PREC, STRIDE>(X, row, co + e, fmaxf(acc[e], 0.0f), ovf);
             }
         }
         }
@@ -591,15 +764,19 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         }
     }
     __syncthreads();
-    const int jrow = lane & 15, gq = lane >> 4;
+    // position-tile rows / lane map of the layer MFMA: 16x16x32 (row = lane & 15, k quarter = lane >> 4) or
+    // 32x32x16 (row = lane & 31, k half = lane >> 5)
+    constexpr int TR = MF ? 32 : 16;
+    const int jrow = lane & (TR - 1), gq = MF ? (lane >> 5) : (lane >> 4);
     // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
-    // waves 0-3 own position tiles [0, NTA), waves 4-7 tiles [NTA, NTA+NTB)
+    // 16x16x32: waves 0-3 own position tiles [0, NTA), waves 4-7 tiles [NTA, NTA+NTB)
+    // 32x32x16: the wave pair (wave >> 1) owns tiles [(wave >> 1) * NTA, +NTA), one 32-cout tile each
     const bool first = wave < 4;
-    const int tbase = first ? 0 : NTA;
+    const int tbase = MF ? (wave >> 1) * NTA : (first ? 0 : NTA);
     int vm[NTA];
 #pragma unroll
     for (int t = 0; t < NTA; t++) {
-        int row = (tbase + t) * 16 + jrow;
+        int row = (tbase + t) * TR + jrow;
         int pos = row % HW, y = pos / W, x = pos - y * W;
         int m = 0;
 #pragma unroll
@@ -609,7 +786,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         }
         vm[t] = row < R ? m : 0;
     }
-    const int rowbase = (tbase * 16 + jrow) * S4 + gq;
+    const int rowbase = (tbase * TR + jrow) * S4 + gq;
     const int zbase = zu; // multiple of 16 units; the per-lane slot is added per tap
     if constexpr (PREC == 0) {
         const size_t wl = (size_t)C * C * 9;
@@ -625,7 +802,10 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         const size_t wl = (size_t)C * C * 9 * 2 * 2 / 16; // 16-byte units per layer (hi + lo halves)
         const int NL = 2 * a.nblocks;
         WPre pre;
-        if (NL > 0) wpre_load<C>(pre, tw4, wave, lane);
+        if (NL > 0) {
+            if constexpr (MF) wpre_load32<C>(pre, tw4, wave, lane);
+            else wpre_load<C>(pre, tw4, wave, lane);
+        }
         unsigned long long stamps[4] = {0, 0, 0, 0};
         unsigned long long tb0 = 0, tb1 = 0, tk0 = 0, tk1 = 0;
         (void)tb0; (void)tb1; (void)tk0; (void)tk1;
@@ -635,8 +815,12 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             const f32x4 *src = (l & 1) ? Y4 : X4;
             f32x4 *dst = (l & 1) ? X4 : Y4;
             const f32x4 *nxt = l + 1 < NL ? tw4 + (size_t)(l + 1) * wl : nullptr;
-            if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
-            else if constexpr (NTB > 0) conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
+            if constexpr (MF) {
+                conv_lds_h3_32<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
+            } else {
+                if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
+                else if constexpr (NTB > 0) conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
+            }
             STAMP(tb0);
             __syncthreads();
             STAMP(tb1);
@@ -668,14 +852,15 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             u128h ah[KS], al[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) { ah[ks].f = wp[(size_t)ks * 128]; al[ks].f = wp[(size_t)ks * 128 + 64]; }
-            const int oc0 = ct * 16 + gq * 4;
+            const int hj = lane & 15, hq = lane >> 4; // this GEMM stays on the 16x16x32 form
+            const int oc0 = ct * 16 + hq * 4;
             f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; r++) if (oc0 + r < OC) bv[r] = a.hb[oc0 + r];
             for (int t = grp; t < NT; t += ngrp) {
-                const int row = t * 16 + jrow;
+                const int row = t * 16 + hj;
                 const int rr = min(row, R - 1);
-                const f32x4 *bp = X4 + (size_t)rr * S4 + gq;
+                const f32x4 *bp = X4 + (size_t)rr * S4 + hq;
                 f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
@@ -715,7 +900,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             const int row = tid;
             float xr[C];
 #pragma unroll
-            for (int c = 0; c < C; c++) xr[c] = act_load<C, PREC>(X, row, c);
+            for (int c = 0; c < C; c++) xr[c] = act_load<C, PREC, STRIDE>(X, row, c);
             const int sidx = row / HW, p = row - sidx * HW;
             for (int oc = 0; oc < OC; oc++) {
                 float acc = a.hb[oc];
@@ -749,7 +934,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
 #endif
 }
 
-template <int C, int NTA, int NTB, int PREC>
+template <int C, int NTA, int NTB, int PREC, int MF = 0>
 __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -803,7 +988,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
             const int nr = n_redo;
             for (int r = 0; r < nr; r++) {
                 const int s0 = redo_grp[r] * S;
-                tower_group<C, NTA, NTB, PREC>(g, a, lds, S, s0, min(S, n - s0));
+                tower_group<C, NTA, NTB, PREC, MF>(g, a, lds, S, s0, min(S, n - s0));
                 __syncthreads();
             }
             return;
@@ -811,7 +996,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     }
     const int s0 = first_sample + blockIdx.x * S;
     if (s0 >= limit) return;
-    tower_group<C, NTA, NTB, PREC>(g, a, lds, S, s0, min(S, limit - s0));
+    tower_group<C, NTA, NTB, PREC, MF>(g, a, lds, S, s0, min(S, limit - s0));
 }
 
 // ------------------------------------------------------------------------------------
@@ -1161,7 +1346,8 @@ NNState *nn_create(const Geo &g, int max_batch, int precision)
     NNState *nn = new NNState();
     nn->g = g;
     nn->max_batch = max_batch;
-    nn->precision = precision;
+    nn->precision = precision == 2 ? 1 : precision; // 2 = the f16x3 arithmetic of 1 on the 32x32x16 MFMA tiling
+    nn->want_mf32 = precision == 2 || getenv("DBAZ_MF32") != nullptr;
     return nn;
 }
 
@@ -1200,6 +1386,7 @@ int nn_configure(NNState *nn, int kind, int channels, int blocks, int head_chann
     int cp = channels <= 16 ? 16 : channels <= 32 ? 32 : channels <= 64 ? 64 : 128;
     if (nn->precision == 1 && cp < 32) cp = 32; // K = 32 per f16 MFMA step
     nn->kind = kind; nn->C = cp; nn->Craw = channels; nn->blocks = blocks; nn->hc = head_channels; nn->vf = value_fc;
+    nn->mf32 = (nn->precision == 1 && nn->want_mf32 && (cp == 64 || cp == 128)) ? 1 : 0; // other widths stay on 16x16x32
     return DBAZ_OK;
 }
 
@@ -1280,14 +1467,18 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
         if (sw > 24) sw = 24;
         if (sw < -24) sw = -24;
         const double wscale = ldexp(1.0, sw);
-        const int KS = C / 32;
+        // fragment order of the layer MFMA: 16x16x32 (cout = lane & 15, k = 8 (lane >> 4) + e of a 32-wide step) or, on the
+        // 32x32x16 tiling, cout = lane & 31, k = 8 (lane >> 5) + e of a 16-wide step; packed [ct][tap][ks][hi|lo][lane][8]
+        const bool mf = nn->mf32 && C % 32 == 0;
+        const int TM = mf ? 32 : 16, TK = mf ? 16 : 32, LS = mf ? 5 : 4;
+        const int KS = C / TK;
         std::vector<_Float16> hp((size_t)C * C * 9 * 2, (_Float16)0.0f);
-        for (int ct = 0; ct < C / 16; ct++)
+        for (int ct = 0; ct < C / TM; ct++)
             for (int tap = 0; tap < 9; tap++)
                 for (int ks = 0; ks < KS; ks++)
                     for (int lane = 0; lane < 64; lane++)
                         for (int e = 0; e < 8; e++) {
-                            int co = ct * 16 + (lane & 15), ci = ks * 32 + 8 * (lane >> 4) + e;
+                            int co = ct * TM + (lane & (TM - 1)), ci = ks * TK + 8 * (lane >> LS) + e;
                             if (co >= Cr || ci >= Cr) continue;
                             float v = (float)((double)(*w)[((size_t)co * Cr + ci) * 9 + tap] * s[co] * wscale);
                             _Float16 h = (_Float16)v;
@@ -1325,6 +1516,31 @@ static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, in
     hipLaunchKernelGGL((k_tower<C, NTA, NTB, 0>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
     return hipSuccess;
 }
+// the f16x3 tower on the 32x32x16 tiling: nt2 position tiles of 32 rows per wave (8 waves = 2 cout tiles x 4 tile groups)
+template <int C>
+static hipError_t tower_inst_mf(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt2, int grid, bool attr_only)
+{
+    if constexpr (C == 64 || C == 128) {
+        if (nt2 == 2) {
+            if (attr_only) return hipFuncSetAttribute((const void *)k_tower<C, 2, 0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds_mf);
+            hipLaunchKernelGGL((k_tower<C, 2, 0, 1, 1>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds_mf, s, nn->g, ta);
+        } else {
+            if (attr_only) return hipFuncSetAttribute((const void *)k_tower<C, 1, 0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds_mf);
+            hipLaunchKernelGGL((k_tower<C, 1, 0, 1, 1>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds_mf, s, nn->g, ta);
+        }
+        return hipSuccess;
+    } else {
+        (void)nn; (void)s; (void)ta; (void)nt2; (void)grid; (void)attr_only;
+        return hipErrorInvalidValue;
+    }
+}
+static hipError_t tower_dispatch_mf(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt2, int grid, bool attr_only)
+{
+    if (nn->C == 64) return tower_inst_mf<64>(nn, s, ta, nt2, grid, attr_only);
+    if (nn->C == 128) return tower_inst_mf<128>(nn, s, ta, nt2, grid, attr_only);
+    return hipErrorInvalidValue;
+}
+
 template <int C>
 static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, int ntt, int grid, bool attr_only, int prec)
 {
@@ -1693,7 +1909,33 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             nn->cus = cus;
     }
+    // 32x32x16 tiling (experimental switch DBAZ_MF32): 8 position tiles of 32 rows per workgroup, rows of C + 4 dwords
+    if (nn->mf32 && (C == 64 || C == 128)) {
+        auto lds_mf = [&](int S_) {
+            const size_t s4 = (C + 4) / 4;
+            const size_t img = ((((size_t)S_ * HW * s4 + 15) & ~(size_t)15) + 3 * s4) * 4;
+            const size_t need0 = (size_t)S_ * 3 * (g.H + 2) * (g.W + 2) + (size_t)27 * C;
+            const size_t need1 = (size_t)2 * hc * (C + 4) + (size_t)S_ * 2 * hc * HW;
+            return (img + std::max(img, std::max(need0, need1))) * 4;
+        };
+        int Sm = MAXROWS / HW;
+        if (Sm > 16) Sm = 16;
+        while (Sm > 1 && lds_mf(Sm) > lds_budget) Sm--;
+        if (Sm >= 1 && lds_mf(Sm) <= lds_budget) {
+            nn->S_mf = Sm;
+            nn->NT2 = (Sm * HW + 31) / 32 > 4 ? 2 : 1;
+            nn->conv_lds_mf = lds_mf(Sm);
+            nn->S_mf_tail = nn->NT2 == 2 ? std::min(128 / HW, Sm - 1) : 0; // <1>: 4 tiles of 32 rows
+            if (nn->S_mf_tail < 0) nn->S_mf_tail = 0;
+        } else {
+            nn->mf32 = 0;
+        }
+    } else {
+        nn->mf32 = 0;
+    }
     hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true);
+    if (he == hipSuccess && nn->mf32) he = tower_dispatch_mf(nn, nullptr, TowerArgs(), 2, 0, true);
+    if (he == hipSuccess && nn->mf32) he = tower_dispatch_mf(nn, nullptr, TowerArgs(), 1, 0, true);
     if (he == hipSuccess && nn->tw32) he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true, 0);
     if (he == hipSuccess && nn->S_mid > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 4, 0, true);
     if (he == hipSuccess && nn->S_small > 0) he = tower_dispatch(nn, nullptr, TowerArgs(), 2, 0, true);
@@ -1742,6 +1984,15 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.S_big = nn->S_big; ta.cus = nn->cus;
     ta.role = 0; ta.S = nn->S;
+    if (nn->mf32) {
+        // 32x32x16 tiling: main launch + one tail launch of half-size workgroups (same split rule, derived from n on the device)
+        ta.S_main = ta.S = nn->S_mf; ta.S_small = nn->S_mf_tail; ta.S_mid = ta.S_big = 0;
+        (void)tower_dispatch_mf(nn, s, ta, nn->NT2, (max_n + nn->S_mf - 1) / nn->S_mf, false);
+        if (nn->S_mf_tail > 0) {
+            ta.role = 1; ta.S = nn->S_mf_tail;
+            (void)tower_dispatch_mf(nn, s, ta, 1, nn->cus, false);
+        }
+    } else {
     (void)tower_dispatch(nn, s, ta, nn->NTT, (max_n + nn->S - 1) / nn->S, false);
     if (nn->S_small > 0) { // tail <= cus * S_small samples: one round of <2,2> workgroups
         ta.role = 1; ta.S = nn->S_small;
@@ -1755,11 +2006,12 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
         ta.role = 3; ta.S = nn->S_big;
         (void)tower_dispatch(nn, s, ta, 5, nn->cus, false);
     }
+    }
     static const bool no_fb = getenv("DBAZ_NO_FALLBACK") != nullptr; // measurement aid only
     if (nn->precision == 1 && nn->tw32 && !no_fb) {
         // safety net of the f16x3 mode: samples whose workgroup saw an activation leave f16's range are redone by the
         // exact-f32 tower (its workgroups check the per-sample flags on the device and leave at once otherwise)
-        ta.role = 0; ta.S = nn->S; ta.S_small = ta.S_mid = ta.S_big = 0; ta.fallback = 1;
+        ta.role = 0; ta.S = ta.S_main = nn->S; ta.S_small = ta.S_mid = ta.S_big = 0; ta.fallback = 1;
         ta.tw = nn->tw32; ta.tb = nn->tb32; ta.w0p = nullptr; ta.hwp = nullptr;
         (void)tower_dispatch(nn, s, ta, nn->NTT, std::min((max_n + nn->S - 1) / nn->S, nn->cus), false, 0);
     }

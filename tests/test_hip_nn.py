@@ -104,17 +104,19 @@ def test_predict_before_commit_is_an_error():
     e.close()
 
 
+@pytest.mark.parametrize("precision", [1, 2])
 @pytest.mark.parametrize("rows,cols,ch,nb,n", [(6, 6, 64, 20, 64), (3, 3, 64, 20, 40), (9, 9, 64, 20, 10), (6, 6, 64, 3, 5),
-                                               (4, 2, 32, 2, 50), (6, 6, 128, 2, 19), (2, 3, 8, 1, 12)])
-def test_f16x3_split_precision_mode(rows, cols, ch, nb, n):
+                                               (4, 2, 32, 2, 50), (6, 6, 128, 2, 19), (2, 3, 8, 1, 12), (6, 6, 64, 2, 1500),
+                                               (5, 3, 64, 2, 700)])
+def test_f16x3_split_precision_mode(rows, cols, ch, nb, n, precision):
     """nn_precision=1: every f32 operand is an error-compensated (hi, lo) pair of halves on the
     f16 MFMA pipe with f32 accumulation.  Same 1e-4 north-star tolerance; the observed error is
     of the order of f32 rounding noise (asserted < 2e-5)."""
     torch.manual_seed(rows * 31 + cols + ch + n)
     m = nn_ref.ResNetZeroRef(rows, cols, ch, nb)
     nn_ref.randomize_bn(m, 5)
-    e = engine_for(rows, cols, m, n_slots=128, precision=1)
-    e0 = engine_for(rows, cols, m, n_slots=128, precision=0)
+    e = engine_for(rows, cols, m, n_slots=max(128, n), precision=precision)  # 2: the same arithmetic on 32x32x16 MFMA tiles
+    e0 = engine_for(rows, cols, m, n_slots=max(128, n), precision=0)
     rng = np.random.RandomState(n)
     X = rng.randint(0, 2, size=(n, 3, rows + 1, cols + 1)).astype(np.float32)
     X[:, 2] = rng.randint(-2, rows * cols + 1, size=(n, 1, 1))

@@ -18,7 +18,8 @@ from dotsboxesaz_amd import _lib
 _lib.LIB_PATH = "gpurun_out/stamp_build/libdbaz_hip.so"
 from dotsboxesaz_amd.engine import Engine
 from dotsboxesaz_amd import nn as dnn
-e = Engine(6, 6, 8192, evaluator="resnet", nn_precision=1)
+import os
+e = Engine(6, 6, 8192, evaluator="resnet", nn_precision=2 if os.environ.get("DBAZ_MF32") else 1)
 torch.manual_seed(0)
 m = dnn.ResNetZero(dnn.resnet_params(6, 6))
 e.load_state_dict(m.state_dict(), "resnet", **m.shape)
@@ -31,12 +32,21 @@ L = _lib.load()
 L.dbaz_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 rc = L.dbaz_debug_read_stamps(e.h, out.ctypes.data, n_wg)
 o = out.astype(np.float64)
+# only workgroups of the MAIN launch that ran: rows of idle entries are zero, and the first `cus` rows were overwritten by a
+# tail launch (smaller workgroups) whenever the batch left a tail
+ran = o[:, 0, 4] > 0
+ran[:256] = False
+o = o[ran]
 tot = o[..., 4]
 print("rc", rc, "waves", (tot > 0).sum())
 names = ["prologue(loads)", "main loop", "epilogue", "barrier wait", "layers total"]
 for i, nme in enumerate(names):
     print("%-18s mean %10.0f cycles/wave   %5.1f %% of layers total" % (nme, o[..., i].mean(), 100 * o[..., i].mean() / tot.mean()))
-print("per layer: total %.0f, main %.0f (MFMA floor 7 tiles: %d, 6 tiles: %d)" % (tot.mean() / 40, o[..., 1].mean() / 40, 18 * 21 * 16, 18 * 18 * 16))
+import os
+if os.environ.get("DBAZ_MF32"):
+    print("32x32x16 tiling, 5 samples per workgroup; per layer: total %.0f, main %.0f (MFMA floor per wave: 36 steps x 6 MFMAs x 32 = %d; per SIMD twice that)" % (tot.mean() / 40, o[..., 1].mean() / 40, 36 * 6 * 32))
+else:
+    print("per layer: total %.0f, main %.0f (MFMA floor 7 tiles: %d, 6 tiles: %d)" % (tot.mean() / 40, o[..., 1].mean() / 40, 18 * 21 * 16, 18 * 18 * 16))
 for w in range(8):
     print("wave", w, ["%.0f" % (o[:, w, i].mean() / 40) for i in range(5)])
 whole = o[..., 7].mean()
