@@ -3,19 +3,12 @@
 # k_tower wave spends its cycles.  Usage on the GPU box: bash tools/stamp_build_run.sh
 set -e
 cd "$(dirname "$0")/.."
-D=gpurun_out/stamp_build
-mkdir -p $D
-for f in tree engine nn replay; do
-  extra=""; [ $f = tree ] && extra="-ffp-contract=off"; [ $f = replay ] && extra="-ffp-contract=off"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DDBAZ_STAMP $extra -c dotsboxesaz_amd/csrc/$f.hip -o $D/$f.o &
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libdbaz_hip.so $D/tree.o $D/engine.o $D/nn.o $D/replay.o
+# the stamped library is built in the build container: tools/build_stamp.sh -> build/stamp/libdbaz_hip.so
 python - <<'PY'
 import ctypes as C, numpy as np, torch, sys
 sys.path.insert(0, ".")
 from dotsboxesaz_amd import _lib
-_lib.LIB_PATH = "gpurun_out/stamp_build/libdbaz_hip.so"
+_lib.LIB_PATH = "build/stamp/libdbaz_hip.so"
 from dotsboxesaz_amd.engine import Engine
 from dotsboxesaz_amd import nn as dnn
 import os
