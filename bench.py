@@ -224,6 +224,40 @@ def full_games(args, rank, local_rank, world, torch):
     print(json.dumps(out), flush=True)
 
 
+def single_tree_bench(args, local_rank, torch):
+    """SURVEY 8f-4 (players.AZPlayer): ONE tree searched for args.single_tree seconds with args.pending simulations in
+    flight (virtual loss, one batched network launch per wave).  Reads per second on the empty board."""
+    eng_args = argparse.Namespace(**vars(args))
+    from dotsboxesaz_amd.engine import Engine
+    from dotsboxesaz_amd import nn as dnn
+    rows = cols = args.board
+    res = {}
+    for K in sorted({1, 8, args.pending}):
+        eng = Engine(rows, cols, 1, mcts_num_read=args.sims, evaluator=args.evaluator, device=local_rank, nn_precision=args.precision,
+                     nodes_per_slot=1 << 20, max_pending_evals=max(K, 2))
+        if args.evaluator == "resnet":
+            torch.manual_seed(0)
+            model = dnn.ResNetZero(dnn.resnet_params(rows, cols, args.channels, args.blocks))
+            eng.load_state_dict(model.state_dict(), "resnet", **model.shape)
+        eng.set_pending(K)
+        eng.set_positions(None)
+        t0 = time.perf_counter()
+        eng.search_timed(args.single_tree, num_reads=2 ** 31 - 1)
+        dt = time.perf_counter() - t0
+        r, c = eng.roots(), eng.counters()
+        reads = int(r["root_nv"][0]) - 1
+        res[str(K)] = {"reads": reads, "seconds": dt, "reads_per_sec": reads / dt, "nn_evals": c["nn_evals"],
+                       "shared_pending_leaves": c["cache_hits"], "mean_path_len": c["sum_path"] / max(1, c["expansions"]),
+                       "most_visited_share": float(r["visits"][0].max()) / max(1, reads), "pool_high_water": c["pool_high_water"]}
+        eng.close()
+    out = {"metric": "single_tree_reads_per_sec", "value": res[str(args.pending)]["reads_per_sec"], "unit": "reads/s", "n_gpus": 1,
+           "higher_is_better": True, "data": "synthetic", "by_pending": res,
+           "config": {"workload": "%dx%d, ONE tree from the empty board, %.1f s wall clock, evaluator=%s %dx%d precision %d, "
+                                  "max_pending_evals=%d" % (rows, cols, args.single_tree, args.evaluator, args.blocks, args.channels,
+                                                            args.precision, args.pending)}}
+    print(json.dumps(out), flush=True)
+
+
 def train_data_bench(args, local_rank, torch):
     """Training DATA path on synthetic replay rows resident in HBM: dataset build
     (stage + stable radix sort + Kahan group means = HDFStoreDataset with pos_average) and batch
@@ -343,6 +377,10 @@ def main():
     ap.add_argument("--full-games", type=int, default=0,
                     help="instead of timing K steps, play this many COMPLETE games from the empty board and report "
                          "games/s and expansions/game measured directly (one JSON line, metric selfplay_games_per_sec)")
+    ap.add_argument("--single-tree", type=float, default=0.0,
+                    help="instead of the self-play step: search ONE tree for this many seconds with --pending simulations in "
+                         "flight (players.AZPlayer's request; one JSON line, metric single_tree_reads_per_sec)")
+    ap.add_argument("--pending", type=int, default=64, help="max_pending_evals of --single-tree")
     ap.add_argument("--train-data", type=int, default=0,
                     help="instead of the self-play step: time the training data path (dataset build + batch assembly) "
                          "on this many synthetic replay rows in HBM (one JSON line, metric train_data_rows_per_sec)")
@@ -351,7 +389,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    special = args.full_games > 0 or args.train_data > 0
+    special = args.full_games > 0 or args.train_data > 0 or args.single_tree > 0
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not special:
         # before anything touches the GPU: the baseline forks one worker process per host core
@@ -368,6 +406,9 @@ def main():
         return
     if args.train_data > 0:
         train_data_bench(args, local_rank, torch)
+        return
+    if args.single_tree > 0:
+        single_tree_bench(args, local_rank, torch)
         return
     eng, m = run_engine(args, args.precision, args.steps, args.warmup, rank, local_rank, world, dist, torch)
     # replay all-gather at iteration end (multi-GPU): whatever finished + a fixed synthetic shard

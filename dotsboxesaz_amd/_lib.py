@@ -19,7 +19,7 @@ SYMBOLS = [
     "dbaz_last_error", "dbaz_version", "dbaz_create", "dbaz_destroy", "dbaz_sync",
     "dbaz_rules_init", "dbaz_rules_valid_moves", "dbaz_rules_play", "dbaz_rules_result", "dbaz_rules_features",
     "dbaz_nn_configure", "dbaz_nn_select_model", "dbaz_nn_set_tensor", "dbaz_nn_commit", "dbaz_nn_predict",
-    "dbaz_set_search_params", "dbaz_set_positions", "dbaz_search", "dbaz_search_begin", "dbaz_select", "dbaz_expand_backup",
+    "dbaz_set_search_params", "dbaz_set_positions", "dbaz_search", "dbaz_search_timed", "dbaz_set_pending", "dbaz_search_begin", "dbaz_select", "dbaz_expand_backup",
     "dbaz_get_roots", "dbaz_get_root_states", "dbaz_advance",
     "dbaz_selfplay_start", "dbaz_selfplay_script", "dbaz_selfplay_fastforward", "dbaz_selfplay_stagger", "dbaz_step", "dbaz_run",
     "dbaz_get_counters", "dbaz_timing_begin", "dbaz_timing_end", "dbaz_fetch_samples", "dbaz_replay_rows_dev",
@@ -36,7 +36,7 @@ class Config(C.Structure):
         ("n_temp", C.c_int32), ("temp_idx", C.c_int32 * 8), ("temp_val", C.c_double * 8),
         ("evaluator", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64), ("max_out_rows", C.c_int32),
         ("nn_precision", C.c_int32), ("match_play", C.c_int32), ("evaluator2", C.c_int32),
-        ("transposition_cache", C.c_int32), ("reserved0", C.c_int32),
+        ("transposition_cache", C.c_int32), ("max_pending_evals", C.c_int32),
     ]
 
 
@@ -97,6 +97,8 @@ def load():
     L.dbaz_set_search_params.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double]
     L.dbaz_set_positions.argtypes = [vp, vp, vp]
     L.dbaz_search.argtypes = [vp, vp, vp]
+    L.dbaz_search_timed.argtypes = [vp, vp, vp, C.c_double]
+    L.dbaz_set_pending.argtypes = [vp, i32]
     L.dbaz_search_begin.argtypes = [vp, vp, vp]
     L.dbaz_select.argtypes = [vp, vp, vp, vp]
     L.dbaz_expand_backup.argtypes = [vp, vp, vp]

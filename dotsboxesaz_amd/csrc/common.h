@@ -31,6 +31,7 @@ struct Geo {
 #define META_DW 16
 #define NF_EXPANDED 1u
 #define NF_TERMINAL 2u
+#define NF_INFLIGHT 4u   // K > 1 search: selected as a leaf in the current wave, evaluation pending
 #define NS_MASK 0x3FFFFFFFu
 #define NS_SAME 0x40000000u
 
@@ -73,6 +74,8 @@ struct Slot {
     int32_t root;            // node index of the current root
     int32_t n_free;          // entries on the free stack (recycled node indices)
     int32_t pend_head, pend_tail; // ring of dropped nodes whose children have not been enumerated yet
+    int32_t wave_sims;       // K > 1 search: simulations selected in the current wave, waiting for expand/backup
+    int32_t first_wave;      // K > 1 search: the first wave of a UCT_search call is min(K, A) wide (mcts.py:228-229)
 };
 
 // device-side reduction of the Slot array (dbaz_get_counters / dbaz_run poll this instead of copying every Slot)
@@ -80,6 +83,12 @@ struct SlotSummary {
     unsigned long long n_search, n_eval, n_hit, n_term, sum_path;
     int32_t active, error, blocked, pool_high;
     int32_t first_error_slot, first_error_code; // lowest slot index in PH_ERROR (or 0x7fffffff) and its code
+};
+
+// one in-flight simulation of a tree searched with several pending evaluations (k_select_multi / k_expand_backup_multi)
+struct SimRec {
+    int32_t leaf, path_len, terminal, result, to_play;
+    int32_t dup;   // its leaf was already selected by an earlier simulation of the same wave (one evaluation serves both)
 };
 
 struct PathEnt {
@@ -111,6 +120,7 @@ struct SearchCfg {
     int table_n;             // entries in pbc/sqrt tables
     int step;                // engine step counter of this launch
     int driver_concurrent;   // this k_select runs next to the driver pass of the same step (self-play stepping)
+    int pending;             // K > 1 search: width of a wave (<= TreeBufs.kmax), dbaz_set_pending
 };
 
 // device buffer bundle handed to the tree kernels
@@ -129,6 +139,14 @@ struct TreeBufs {
     int32_t *n_eval;   // [2] list lengths
     int32_t *pend;     // [n_slots][cap] ring: dropped nodes waiting for the collector (their child rows are still needed)
     int32_t *freel;    // [n_slots][cap] stack: node indices ready for reuse
+    // search with K > 1 pending evaluations per tree (buffers exist when dbaz_config.max_pending_evals > 1)
+    int32_t kmax;         // simulations in flight per tree
+    SimRec *simrec;       // [n_slots][kmax]
+    PathEnt *path_m;      // [n_slots][kmax][dmax]
+    float *feat_m;        // [n_slots * kmax][3*HW]
+    float *evalP_m;       // [n_slots * kmax][AS]
+    float *evalV_m;       // [n_slots * kmax]
+    int32_t *list_m;      // [n_slots * kmax] entries slot * kmax + k needing an evaluation
     int32_t *drv_list;  // [n_slots] slots that need the driver this step (k_driver_scan)
     int32_t *drv_count; // [1]
     unsigned long long *tt; // [n_slots][tt_mask+1] transposition table (tag24 | epoch8 | node index), nullptr = off

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -171,6 +172,9 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
         return set_error(nullptr, DBAZ_EINVAL, "match play needs two device evaluators");
     if (cfg->n_temp < 0 || cfg->n_temp > 8) return set_error(nullptr, DBAZ_EINVAL, "n_temp must be in 0..8");
     if (cfg->transposition_cache < 0 || cfg->transposition_cache > 2) return set_error(nullptr, DBAZ_EINVAL, "transposition_cache must be 0, 1 or 2");
+    if (cfg->max_pending_evals < 0 || cfg->max_pending_evals > 1024) return set_error(nullptr, DBAZ_EINVAL, "max_pending_evals must be in 0..1024");
+    if (cfg->max_pending_evals > 1 && (cfg->evaluator == DBAZ_EVAL_EXTERNAL || cfg->match_play))
+        return set_error(nullptr, DBAZ_EINVAL, "max_pending_evals > 1 needs a device evaluator and no match play");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -221,6 +225,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     for (int i = 0; i < cfg->n_temp; i++) { sc.temp_idx[i] = cfg->temp_idx[i]; sc.temp_val[i] = cfg->temp_val[i]; }
     sc.evaluator = cfg->evaluator; sc.seed = cfg->seed;
     sc.match_play = cfg->match_play ? 1 : 0; sc.evaluator2 = cfg->evaluator2;
+    sc.pending = cfg->max_pending_evals > 1 ? cfg->max_pending_evals : 1;
 
     TreeBufs &B = e->B;
     memset(&B, 0, sizeof(B));
@@ -242,6 +247,16 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     CREATE_CHECK(dmalloc(e, &B.n_eval, 4));
     CREATE_CHECK(dmalloc(e, &B.pend, ns * g.cap, false));
     CREATE_CHECK(dmalloc(e, &B.freel, ns * g.cap, false));
+    B.kmax = cfg->max_pending_evals > 1 ? cfg->max_pending_evals : 1;
+    if (B.kmax > 1) {
+        const size_t nk = ns * (size_t)B.kmax;
+        CREATE_CHECK(dmalloc(e, &B.simrec, nk));
+        CREATE_CHECK(dmalloc(e, &B.path_m, nk * g.dmax));
+        CREATE_CHECK(dmalloc(e, &B.feat_m, nk * F));
+        CREATE_CHECK(dmalloc(e, &B.evalP_m, nk * g.AS));
+        CREATE_CHECK(dmalloc(e, &B.evalV_m, nk));
+        CREATE_CHECK(dmalloc(e, &B.list_m, nk));
+    }
     CREATE_CHECK(dmalloc(e, &B.drv_list, ns));
     CREATE_CHECK(dmalloc(e, &B.drv_count, 4));
     B.tt = nullptr;
@@ -289,7 +304,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     }
     B.first_game = 0;
     B.last_game = 0;
-    e->nns[0] = nn_create(g, e->n_slots, cfg->nn_precision);
+    e->nns[0] = nn_create(g, e->n_slots * B.kmax, cfg->nn_precision);
     e->nns[1] = nn_create(g, e->n_slots, cfg->nn_precision);
     e->nn = e->nns[0];
     CREATE_HIP(hipStreamSynchronize(e->stream));
@@ -555,9 +570,30 @@ static hipEvent_t next_event(dbaz_engine *e)
     return e->ev_pool[e->ev_used++];
 }
 
+// one WAVE of up to K simulations for every searching tree (max_pending_evals = K > 1): K sequential selections with
+// virtual loss per tree, one batched evaluation of all their leaves, expand + backup in selection order
+static int sim_wave(dbaz_engine *e)
+{
+    hipStream_t s = e->stream;
+    const bool use_nn = e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN;
+    e->sc.step = (int)(e->steps & 0x3FFFFFFF) + 1;
+    e->sc.driver_concurrent = 0;
+    if (use_nn) HIP_CHECK_RET(e, hipMemsetAsync(e->B.n_eval, 0, 8, s));
+    tree_launch_select_multi(s, e->g, e->sc, e->B, e->n_slots);
+    if (use_nn) {
+        nn_forward(e->nns[0], s, e->B.feat_m, e->B.list_m, e->B.n_eval, e->n_slots * e->B.kmax, e->B.evalP_m, e->B.evalV_m, e->g.AS, nullptr, nullptr);
+        e->nn_launches++;
+    }
+    tree_launch_expand_backup_multi(s, e->g, e->sc, e->B, e->n_slots);
+    e->steps++;
+    HIP_CHECK_RET(e, hipGetLastError());
+    return DBAZ_OK;
+}
+
 // one simulation step for every searching slot
 static int sim_step(dbaz_engine *e, bool with_driver)
 {
+    if (e->B.kmax > 1 && !with_driver) return sim_wave(e);
     hipStream_t s = e->stream;
     auto is_nn = [](int ev) { return ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN; };
     const bool use_nn = is_nn(e->sc.evaluator);
@@ -643,8 +679,53 @@ extern "C" int dbaz_search_begin(dbaz_engine *e, const int32_t *num_reads, const
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
     int mx = e->sc.mcts_num_read;
     if (num_reads) { mx = 0; for (int i = 0; i < e->n_slots; i++) mx = std::max(mx, num_reads[i]); }
-    e->search_iters_left = mx + 1;
+    e->search_iters_left = e->B.kmax > 1 ? (mx + e->sc.pending - 1) / e->sc.pending + 2 : mx + 1;
     e->search_open = true;
+    return DBAZ_OK;
+}
+
+extern "C" int dbaz_set_pending(dbaz_engine *e, int32_t k)
+{
+    if (!e) return DBAZ_EINVAL;
+    if (e->B.kmax <= 1) return set_error(e, DBAZ_ESTATE, "the handle was created with max_pending_evals <= 1");
+    if (k < 1 || k > e->B.kmax) return set_error(e, DBAZ_EINVAL, "pending evaluations must be in 1..%d", e->B.kmax);
+    e->sc.pending = k;
+    return DBAZ_OK;
+}
+
+extern "C" int dbaz_search_timed(dbaz_engine *e, const int32_t *num_reads, const double *noise, double time_limit_s)
+{
+    if (!e) return DBAZ_EINVAL;
+    if (e->sc.evaluator == DBAZ_EVAL_EXTERNAL)
+        return set_error(e, DBAZ_ESTATE, "external evaluator: use dbaz_search_begin/dbaz_select/dbaz_expand_backup");
+    if ((e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN) && !nn_ready(e->nns[0]))
+        return set_error(e, DBAZ_ESTATE, "network weights not committed (dbaz_nn_commit)");
+    // end_time = time.time() + (time_limit or 120), mcts.py:201-203
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(time_limit_s > 0 ? time_limit_s : 120.0);
+    int r = dbaz_search_begin(e, num_reads, noise);
+    if (r) return r;
+    // the root expansion is not subject to the clock (mcts.py:207-208); afterwards the clock is looked at between waves
+    // (one wave = K reads per tree; with K = 1 every 8 steps)
+    const int per_check = e->B.kmax > 1 ? 1 : 8;
+    bool first = true;
+    for (;;) {
+        for (int i = 0; i < (first ? 1 : per_check); i++) {
+            r = sim_step(e, false);
+            if (r) return r;
+        }
+        first = false;
+        int32_t c[4];
+        r = count_phases(e, c);
+        if (r) return r;
+        if (c[2] > 0) { e->search_open = false; return check_slot_errors(e); }
+        if (c[0] == 0) break;
+        if (std::chrono::steady_clock::now() > t_end) { // mcts.py:232-233: the remaining reads are not started
+            tree_launch_stop_search(e->stream, e->B, e->n_slots);
+            HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
+            break;
+        }
+    }
+    e->search_open = false;
     return DBAZ_OK;
 }
 

@@ -464,6 +464,8 @@ __device__ void begin_search(const Geo &g, const SearchCfg &cfg, const TreeBufs 
         }
     }
     S->sims_left = num_reads;
+    S->first_wave = 1;
+    S->wave_sims = 0;
     if (rm.flags & NF_EXPANDED) {
         root_prep(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
         set_phase_stamped(S, num_reads > 0 ? PH_SIMS : PH_READY, cfg.step);
@@ -821,6 +823,294 @@ __global__ void __launch_bounds__(WAVE * SELECT_WAVES) k_select(Geo g, SearchCfg
     if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(B.n_eval + threadIdx.x, s_cnt[threadIdx.x]);
     __syncthreads();
     if (my >= 0) (model ? B.eval_list2 : B.eval_list)[s_base[model] + my] = slot;
+}
+
+// ------------------------------------------------------------------------------------
+// UCT_search with K > 1 pending evaluations on ONE tree (mcts.py:228-239; players.AZPlayer).
+// A wave of the search = up to K simulations selected ONE AFTER THE OTHER by the tree's wavefront, each leaving a
+// virtual loss on its leaf path, then ONE batched evaluation of their leaves, then their expand + backup in the same
+// order.  Virtual loss: exactly the reference's `total_value -= VIRTUAL_LOSS` on every node a simulation leaves
+// (mcts.py:108-109; restored by backup's `+ VIRTUAL_LOSS`), plus what the reference lacks -- the visit is counted on
+// every edge of the path, the leaf's included, at SELECT time instead of at backup time, so that the simulations of a
+// wave spread over the tree instead of piling onto one leaf (with K = 64 the reference's in-flight leaves are
+// 98 % duplicates).  A leaf that is selected again while its evaluation is pending is not evaluated twice (NF_INFLIGHT).
+// With K = 1 every number equals the sequential kernels' (and the oracle's) bit for bit: a simulation never reads a
+// count it has itself incremented.
+// ------------------------------------------------------------------------------------
+template <int NPL>
+__device__ __forceinline__ void select_multi_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, int lane)
+{
+    Slot *S = B.slots + slot;
+    const int phase = S->phase;
+    if (phase != PH_EXPAND_ROOT && phase != PH_SIMS) return;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    const double *rprior = B.root_prior + (size_t)slot * g.AS;
+    const int A = g.A, K = B.kmax;
+    int width = min(max(cfg.pending, 1), K);
+    if (S->first_wave) width = min(width, A);                 // max_pend = min(max_pending_evals, len(valid_moves))
+    int n_sims = phase == PH_EXPAND_ROOT ? 1 : min(width, S->sims_left);
+    PoolState q = pool_load(S);
+    const int root = S->root;
+    int err = 0, done = 0;
+    for (int k = 0; k < n_sims && !err; k++) {
+        PathEnt *path = B.path_m + ((size_t)slot * K + k) * g.dmax;
+        pool_collect<GC_PER_STEP>(g, B, slot, pool, q, lane);
+        int cur = root, depth = 0, in_move;
+        int Nself = S->root_N;
+        NodeMeta m = load_meta(pool, g, root);
+        NodeRows<NPL> R;
+        load_rows<NPL>(R, pool, g, root, lane);
+        double pbc_cur, sq_cur;
+        select_tab(cfg, B, Nself, pbc_cur, sq_cur);
+        select_tab_fix(cfg, Nself, pbc_cur, sq_cur);
+        double rp[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; j++) rp[j] = (lane + WAVE * j < A) ? rprior[lane + WAVE * j] : 0.0;
+        in_move = m.move;
+        if (lane == 0) {
+            S->root_N = Nself + 1;                              // the visit is counted now (backup adds the value only)
+            if ((m.flags & NF_EXPANDED) && !(m.flags & NF_TERMINAL)) S->root_W = S->root_W - 1.0f;
+        }
+        while ((m.flags & NF_EXPANDED) && !(m.flags & NF_TERMINAL)) {
+            uint32_t *nd = node_ptr(pool, g, cur);
+            float *Wrow = reinterpret_cast<float *>(nd + META_DW + g.AS);
+            uint32_t *NSrow = nd + META_DW + 2 * g.AS;
+            int32_t *Crow = reinterpret_cast<int32_t *>(nd + META_DW + 3 * g.AS);
+            const double pbc0 = pbc_cur, sq = sq_cur;
+            const uint64_t ew[4] = {m.st.e0, m.st.e1, m.st.e2, m.st.e3};
+            double bx = 0.0;
+            int bj = 0;
+            float bw = 0.0f;
+            uint32_t bns = 0;
+            int bc = -1;
+            bool have = false;
+#pragma unroll
+            for (int j = 0; j < NPL; j++) {
+                const int i = lane + WAVE * j;
+                const bool in = i < A;
+                const double P = (cur == root) ? rp[j] : (double)R.P[j];
+                const float w = R.W[j];
+                const uint32_t ns = R.NS[j];
+                const int n = (int)(ns & NS_MASK);
+                const double sgn = (ns & NS_SAME) ? 1.0 : -1.0;
+                const double t = sq / (double)(n + 1);
+                const double pb_c = pbc0 * t;
+                const double prior_score = pb_c * P;
+                double value_score = (double)w / (double)(1 + n);
+                value_score = value_score * sgn;
+                const double score = prior_score + value_score;
+                const bool valid = in && !(((ew[j] | g.sentinel[j]) >> lane) & 1ull);
+                const double inval = valid ? 0.0 : 1.0;
+                const double x = -1e12 * inval + score;
+                const bool take = in && (!have || (bx == bx && !(x <= bx)));
+                bx = take ? x : bx;
+                bj = take ? j : bj;
+                bw = take ? w : bw;
+                bns = take ? ns : bns;
+                bc = take ? R.C[j] : bc;
+                have = have || take;
+            }
+            int bi = have ? lane + WAVE * bj : 0x7fffffff;
+            {   // numpy argmax order (first maximum; the first NaN wins): generic butterfly
+                double rx = bx;
+                bool rh = have;
+                for (int o = 32; o > 0; o >>= 1) {
+                    double ox = __shfl_xor(rx, o);
+                    int oi = __shfl_xor(bi, o);
+                    int oh = __shfl_xor((int)rh, o);
+                    if (cand_beats(ox, oi, oh != 0, rx, bi, rh)) { rx = ox; bi = oi; rh = true; }
+                }
+            }
+            bi = __builtin_amdgcn_readfirstlane(bi);
+            const int owner = bi & (WAVE - 1);
+            bw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bw), owner));
+            bns = (uint32_t)__builtin_amdgcn_readlane((int)bns, owner);
+            int child = __builtin_amdgcn_readlane(bc, owner);
+            if (lane == 0) {
+                PathEnt pe;
+                pe.node = cur; pe.move_in = (int16_t)in_move; pe.to_play = (int16_t)m.st.to_play;
+                path[depth] = pe;
+            }
+            depth++;
+            if (child < 0) {
+                child = pool_alloc(g, B, slot, pool, q, lane);
+                if (child < 0) { err = DBAZ_EPOOL; depth--; break; }
+                GState st = m.st;
+                int r = gs_play(g, st, bi, nullptr);
+                if (r < 0) { err = DBAZ_EILLEGAL; depth--; break; }
+                bool same = (st.to_play == st.just_played);
+                if (lane == 0) {
+                    Crow[bi] = child;
+                    NSrow[bi] = (same ? NS_SAME : 0u) | 1u;   // child_player_changed slot; the pending visit
+                }
+                init_node(pool, g, child, st, cur, bi, m.deepness + 1, lane);
+                NodeMeta cm;
+                cm.st = st; cm.parent = cur; cm.move = bi;
+                cm.result = gs_result(st);
+                cm.flags = (cm.result != DBAZ_RESULT_NONE) ? NF_TERMINAL : 0;
+                cm.deepness = m.deepness + 1;
+                cur = child; in_move = bi; m = cm;
+                break;
+            }
+            const int nchild = (int)(bns & NS_MASK);
+            double pbc_nx, sq_nx;
+            select_tab(cfg, B, nchild, pbc_nx, sq_nx);
+            NodeMeta cm = load_meta(pool, g, child);
+            load_rows<NPL>(R, pool, g, child, lane);
+            select_tab_fix(cfg, nchild, pbc_nx, sq_nx);
+            if (lane == owner) {
+                NSrow[bi] = bns + 1u;                           // the visit of the edge into `child`, counted now
+                if ((cm.flags & NF_EXPANDED) && !(cm.flags & NF_TERMINAL)) Wrow[bi] = bw - 1.0f; // VIRTUAL_LOSS on the node left next
+            }
+            if ((cm.flags & NF_EXPANDED) && !(cm.flags & NF_TERMINAL)) {
+                Nself = nchild;
+                pbc_cur = pbc_nx;
+                sq_cur = sq_nx;
+            }
+            cur = child; in_move = bi; m = cm;
+        }
+        if (err) break;
+        // leaf bookkeeping of simulation k
+        const bool term = (m.flags & NF_TERMINAL) != 0;
+        const bool dup = !term && (m.flags & NF_INFLIGHT);
+        if (lane == 0) {
+            PathEnt pe;
+            pe.node = cur; pe.move_in = (int16_t)in_move; pe.to_play = (int16_t)m.st.to_play;
+            path[depth] = pe;
+            SimRec sr;
+            sr.leaf = cur; sr.path_len = depth + 1; sr.terminal = term ? 1 : 0; sr.result = m.result; sr.to_play = m.st.to_play;
+            sr.dup = dup ? 1 : 0;
+            B.simrec[(size_t)slot * K + k] = sr;
+            if (!term && !dup)
+                node_ptr(pool, g, cur)[11] = pack_dw11(m.flags | NF_INFLIGHT, m.result, m.deepness);
+        }
+        if (!term && !dup) {
+            float *f = B.feat_m + ((size_t)slot * K + k) * 3 * g.HW;
+            for (int i = lane; i < 3 * g.HW; i += WAVE) f[i] = (float)gs_feature(g, m.st, i);
+        }
+        done = k + 1;
+        // the next simulation of this wave reads what this one wrote (same wavefront: program order + a drain)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    if (lane == 0) {
+        if (err) { S->error = err; S->phase = PH_ERROR; }
+        S->wave_sims = done;
+        S->sel_step = cfg.step;
+        S->first_wave = 0;
+        pool_store(q, S);
+        if (q.n_nodes > S->pool_high) S->pool_high = q.n_nodes;
+    }
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(WAVE) k_select_multi(Geo g, SearchCfg cfg, TreeBufs B, int n_slots)
+{
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot >= n_slots) return;
+    select_multi_one<NPL>(g, cfg, B, slot, lane);
+    __syncthreads();
+    // evaluation list: the wave's simulations that need the network, in simulation order
+    const Slot *S = B.slots + slot;
+    if (S->phase == PH_ERROR) return;
+    const int K = B.kmax, n = S->wave_sims;
+    const bool nn_ev = cfg.evaluator == DBAZ_EVAL_RESNET || cfg.evaluator == DBAZ_EVAL_SIMPLENN;
+    if (!nn_ev || S->sel_step != cfg.step) return;
+    for (int k0 = 0; k0 < n; k0 += WAVE) {
+        const int k = k0 + lane;
+        bool need = false;
+        if (k < n) {
+            const SimRec sr = B.simrec[(size_t)slot * K + k];
+            need = !sr.terminal && !sr.dup;
+        }
+        const unsigned long long mk = __ballot(need);
+        int base = 0;
+        if (lane == 0 && mk) base = atomicAdd(B.n_eval, (int)__popcll(mk));
+        base = __shfl(base, 0);
+        if (need) B.list_m[base + (int)__popcll(mk & ((1ull << lane) - 1ull))] = slot * K + k;
+    }
+}
+
+__global__ void __launch_bounds__(WAVE) k_expand_backup_multi(Geo g, SearchCfg cfg, TreeBufs B)
+{
+    __shared__ float ldsf[DBAZ_MAX_A];
+    __shared__ double ldsd[DBAZ_MAX_A];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    Slot *S = B.slots + slot;
+    const int phase = S->phase;
+    if (phase != PH_EXPAND_ROOT && phase != PH_SIMS) return;
+    if (S->sel_step != cfg.step) return;
+    uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
+    const int A = g.A, K = B.kmax, n = S->wave_sims;
+    const int ev = cfg.evaluator;
+    const bool formula = ev == DBAZ_EVAL_FORMULA_HASH || ev == DBAZ_EVAL_FORMULA_UNIFORM;
+    int sims_left = S->sims_left;
+    for (int k = 0; k < n; k++) {
+        const SimRec sr = B.simrec[(size_t)slot * K + k];
+        const PathEnt *path = B.path_m + ((size_t)slot * K + k) * g.dmax;
+        NodeMeta lm = load_meta(pool, g, sr.leaf);
+        uint32_t *nd = node_ptr(pool, g, sr.leaf);
+        float v;
+        if (sr.terminal) {
+            v = (float)lm.result;
+        } else if (lm.flags & NF_EXPANDED) {
+            v = __uint_as_float(nd[12]); // expanded by an earlier simulation of this wave (sr.dup): same (p, v)
+        } else {
+            float *Prow = reinterpret_cast<float *>(nd + META_DW);
+            uint64_t h = 0;
+            if (formula) h = formula_hash(lm.st);
+            const float *ep = B.evalP_m + ((size_t)slot * K + k) * g.AS;
+            __syncthreads();
+            for (int i = lane; i < A; i += WAVE) {
+                float p = formula ? formula_p(h, i, ev) : ep[i];
+                ldsf[i] = p * (gs_valid(g, lm.st, i) ? 1.0f : 0.0f);
+            }
+            __syncthreads();
+            float s = np_pairwise_sum<float>(ldsf, A, lane);
+            const bool renorm = (s > 0.0f) && (s != 1.0f);
+            for (int i = lane; i < A; i += WAVE) Prow[i] = renorm ? ldsf[i] / s : ldsf[i];
+            v = formula ? formula_v(h, ev) : B.evalV_m[(size_t)slot * K + k];
+            if (lane == 0) nd[12] = __float_as_uint(v);
+        }
+        if (lane == 0) nd[11] = pack_dw11((lm.flags | NF_EXPANDED) & ~NF_INFLIGHT, lm.result, lm.deepness);
+        // backup: W += v_n + VIRTUAL_LOSS on every path node; the visits were counted at selection
+        const int tp = lm.st.to_play;
+        for (int d = lane; d < sr.path_len; d += WAVE) {
+            PathEnt pe = path[d];
+            float vn = (pe.to_play == tp) ? v : -v;
+            float add = vn + 1.0f;
+            if (d == 0) {
+                S->root_W = S->root_W + add;
+            } else {
+                uint32_t *pn = node_ptr(pool, g, path[d - 1].node);
+                float *Wr = reinterpret_cast<float *>(pn + META_DW + g.AS);
+                Wr[pe.move_in] = Wr[pe.move_in] + add;
+            }
+        }
+        if (lane == 0) {
+            const int term = sr.terminal;
+            S->terminal_count += term;
+            if (lm.deepness > S->max_deepness) S->max_deepness = lm.deepness;
+            S->n_search += 1;
+            S->sum_path += sr.path_len;
+            S->n_term += term;
+            S->n_eval += (term || sr.dup) ? 0 : 1;
+            S->n_hit += sr.dup ? 1 : 0;
+        }
+        if (phase != PH_EXPAND_ROOT) sims_left--;
+        // the next simulation's path shares nodes with this one (same wavefront: program order + a drain)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (phase == PH_EXPAND_ROOT) {
+        root_prep(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
+        if (lane == 0) set_phase_stamped(S, S->sims_left > 0 ? PH_SIMS : PH_READY, cfg.step);
+    } else if (lane == 0) {
+        S->sims_left = sims_left;
+        if (sims_left <= 0) set_phase_stamped(S, PH_READY, cfg.step);
+    }
+    if (lane == 0) S->wave_sims = 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1455,6 +1745,15 @@ __global__ void k_slot_error_code(TreeBufs B, SlotSummary *out)
     if (out->first_error_slot != 0x7fffffff) out->first_error_code = B.slots[out->first_error_slot].error;
 }
 
+// wall-clock cut-off of UCT_search (mcts.py:232-233): the reads that were not started are dropped
+__global__ void k_stop_search(TreeBufs B, int n_slots)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    Slot *S = B.slots + i;
+    if (S->phase == PH_SIMS) { S->sims_left = 0; S->phase = PH_READY; }
+}
+
 __global__ void k_count_active(TreeBufs B, int n_slots, int32_t *out /*[3]: searching, ready, error*/)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1528,6 +1827,19 @@ void tree_launch_select(hipStream_t s, const Geo &g, const SearchCfg &c, const T
     default: hipLaunchKernelGGL(k_select<4>, dim3((n_slots + SELECT_WAVES - 1) / SELECT_WAVES), dim3(WAVE * SELECT_WAVES), 0, s, g, c, B, n_slots); break;
     }
 }
+void tree_launch_select_multi(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
+{
+    switch ((g.A + WAVE - 1) / WAVE) {
+    case 1: hipLaunchKernelGGL(k_select_multi<1>, dim3(n_slots), dim3(WAVE), 0, s, g, c, B, n_slots); break;
+    case 2: hipLaunchKernelGGL(k_select_multi<2>, dim3(n_slots), dim3(WAVE), 0, s, g, c, B, n_slots); break;
+    case 3: hipLaunchKernelGGL(k_select_multi<3>, dim3(n_slots), dim3(WAVE), 0, s, g, c, B, n_slots); break;
+    default: hipLaunchKernelGGL(k_select_multi<4>, dim3(n_slots), dim3(WAVE), 0, s, g, c, B, n_slots); break;
+    }
+}
+void tree_launch_expand_backup_multi(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
+{
+    hipLaunchKernelGGL(k_expand_backup_multi, dim3(n_slots), dim3(WAVE), 0, s, g, c, B);
+}
 void tree_launch_expand_backup(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
 {
     hipLaunchKernelGGL(k_expand_backup, dim3(n_slots), dim3(WAVE), 0, s, g, c, B);
@@ -1564,6 +1876,10 @@ void tree_launch_get_leaves(hipStream_t s, const Geo &g, const TreeBufs &B, int 
                             uint8_t *need_eval, int32_t *n_active)
 {
     hipLaunchKernelGGL(k_get_leaves, dim3(n_slots), dim3(WAVE), 0, s, g, B, n_slots, leaf_x, need_eval, n_active);
+}
+void tree_launch_stop_search(hipStream_t s, const TreeBufs &B, int n_slots)
+{
+    hipLaunchKernelGGL(k_stop_search, dim3((n_slots + 255) / 256), dim3(256), 0, s, B, n_slots);
 }
 void tree_launch_count_active(hipStream_t s, const TreeBufs &B, int n_slots, int32_t *out3)
 {

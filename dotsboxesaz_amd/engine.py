@@ -30,7 +30,8 @@ class Engine:
 
     def __init__(self, rows, cols, n_slots, mcts_num_read=800, cpuct=(1.25, 19652), noise=(0.0, 0.0),
                  temperature=None, reuse_tree=True, evaluator="formula", nodes_per_slot=0, seed=0, device=0,
-                 max_out_rows=0, nn_precision=0, match_play=False, evaluator2="formula", transposition_cache=True):
+                 max_out_rows=0, nn_precision=0, match_play=False, evaluator2="formula", transposition_cache=True,
+                 max_pending_evals=1):
         self._L = _lib.load()
         self.rows, self.cols = int(rows), int(cols)
         self.H, self.W = self.rows + 1, self.cols + 1
@@ -55,6 +56,7 @@ class Engine:
         cfg.evaluator2 = self.EVALUATORS[evaluator2] if isinstance(evaluator2, str) else int(evaluator2)
         # True: on for network evaluators; False: off; "force": on for the formula evaluators too (parity tests)
         cfg.transposition_cache = 2 if transposition_cache == "force" else (0 if transposition_cache else 1)
+        cfg.max_pending_evals = int(max_pending_evals)
         self.cfg = cfg
         self._drained = []
         self.h = C.c_void_p()
@@ -184,6 +186,15 @@ class Engine:
     def search(self, num_reads=None, noise=None):
         nr, nz = self._search_args(num_reads, noise)
         self._ck(self._L.dbaz_search(self.h, _p(nr), _p(nz)))
+
+    def set_pending(self, k):
+        """max_pending_evals of the following searches (1..the handle's max_pending_evals)."""
+        self._ck(self._L.dbaz_set_pending(self.h, int(k)))
+
+    def search_timed(self, time_limit, num_reads=None, noise=None):
+        """UCT_search with its wall-clock cut-off (seconds; None / 0 = the reference's 120 s default)."""
+        nr, nz = self._search_args(num_reads, noise)
+        self._ck(self._L.dbaz_search_timed(self.h, _p(nr), _p(nz), float(time_limit or 0.0)))
 
     def search_external(self, evaluate, num_reads=None, noise=None):
         """UCT_search with a host evaluator: evaluate(x int16 [m,3,H,W]) -> (p [m,A], v [m])."""

@@ -7,9 +7,10 @@
 The tree lives on the GPU (one engine slot, external-evaluator mode): select / expand /
 backup / re-root are the HIP kernels; `async_nn(game_state) -> (p[A], v[1])` is any python
 coroutine, as in the reference.  Semantics are the reference's sequential ones
-(max_pending_evals = 1; the argument is accepted and ignored).  `time_limit` works as in the
-reference (mcts.py:201-203,232-233): the wall clock is checked before every read, default
-120 s; players.AZPlayer's `UCT_search(root, int(1e12), ..., time_limit=t)` pattern is supported.
+with a python `async_nn` (max_pending_evals is then accepted and ignored); a root created with a network
+(`create_root_uct_node(state, nn=...)`) is searched on the device with up to max_pending_evals simulations
+of the one tree in flight (see players.py).  `time_limit` works as in the reference
+(mcts.py:201-203,232-233, default 120 s): players.AZPlayer's `UCT_search(root, int(1e12), ..., time_limit=t)`.
 Dirichlet noise is drawn from numpy's global RNG exactly where the reference draws it.
 """
 import time
@@ -93,14 +94,27 @@ class UCTNode:
         return TreeStats(int(r["stats"][0, 0]), int(r["stats"][0, 1]), int(r["stats"][0, 2]), r["q"][0])
 
 
-def create_root_uct_node(game_state, nodes_per_slot=0, mcts_num_read=800):
-    """mcts.py:156-160"""
+def create_root_uct_node(game_state, nodes_per_slot=0, mcts_num_read=800, nn=None, max_pending_evals=64, nn_precision=1,
+                         device=0):
+    """mcts.py:156-160.  With `nn` (a NeuralNetWrapper, or a weight container such as nn.ResNetZero) the
+    tree's evaluator is the HIP network of this handle and UCT_search keeps up to `max_pending_evals`
+    simulations of the tree in flight (players.AZPlayer's use); without it, `async_nn` of UCT_search is
+    awaited for every leaf (any python coroutine, sequential search)."""
     r, c = game_state._dim
-    e = Engine(r, c, 1, mcts_num_read=mcts_num_read, evaluator="external", nodes_per_slot=nodes_per_slot)
+    model = getattr(nn, "model", nn)
+    if model is None:
+        e = Engine(r, c, 1, mcts_num_read=mcts_num_read, evaluator="external", nodes_per_slot=nodes_per_slot, device=device)
+    else:
+        e = Engine(r, c, 1, mcts_num_read=mcts_num_read, evaluator=model.kind, nodes_per_slot=nodes_per_slot or (1 << 19),
+                   nn_precision=nn_precision if model.kind == "resnet" else 0, device=device,
+                   max_pending_evals=max(1, int(max_pending_evals)))
+        e.load_state_dict(model.state_dict(), model.kind, **model.shape)
     # to_play and the scores depend on the ORDER of the moves, so the position is installed on the
     # device by replaying the state's recorded move history
     e.set_positions([list(game_state._moves)])
-    return UCTNode(e, game_state, None)
+    node = UCTNode(e, game_state, None)
+    node._device_nn = model is not None
+    return node
 
 
 async def UCT_search(root_node, num_reads, async_nn, cpuct=(1.25, 19652), max_pending_evals=64, dirichlet=(0.0, 0.0),
@@ -113,12 +127,22 @@ async def UCT_search(root_node, num_reads, async_nn, cpuct=(1.25, 19652), max_pe
     if alpha > 0:
         # valid_actions*alpha is alpha for EVERY slot in the reference (mcts.py:220-222)
         noise = np.random.dirichlet(np.full(e.A, alpha), 1).reshape(1, e.A)
+    reads = int(min(int(num_reads), 2 ** 31 - 1))
+
+    if getattr(root_node, "_device_nn", False):
+        # evaluator on the device: waves of up to max_pending_evals simulations of this tree, one batched network
+        # launch per wave, the clock read between waves (dbaz_search_timed); `async_nn` is not called
+        kmax = int(e.cfg.max_pending_evals)
+        if kmax > 1:
+            e.set_pending(max(1, min(int(max_pending_evals), kmax)))
+        e.search_timed(time_limit, reads, noise)
+        root_node._refresh()
+        return root_node.child_number_visits
 
     # drive select / evaluate / expand+backup by hand so that async_nn can be awaited
     import ctypes as C
-    from . import _lib
     end_time = time.time() + (time_limit if time_limit else 120)  # mcts.py:201-203
-    nr = np.full(1, int(min(int(num_reads), 2 ** 31 - 1)), np.int32)
+    nr = np.full(1, reads, np.int32)
     first = not root_node.is_expanded  # the root expansion is not subject to the clock (mcts.py:207-208)
     e._ck(e._L.dbaz_search_begin(e.h, nr.ctypes.data, noise.ctypes.data if noise is not None else None))
     x = np.zeros((1, 3, e.H, e.W), np.int16)
@@ -147,4 +171,6 @@ def init_mcts_tree(previous_node, move, reuse_tree=True):
     e = previous_node._e
     e.advance([int(move)], reuse_tree)
     gs = previous_node.game_state.play(int(move))
-    return UCTNode(e, gs, int(move))
+    node = UCTNode(e, gs, int(move))
+    node._device_nn = getattr(previous_node, "_device_nn", False)
+    return node

@@ -76,7 +76,9 @@ typedef struct {
     int32_t transposition_cache; /* 0 = on for network evaluators (default), 1 = off, 2 = on for network AND formula
                              * evaluators (parity tests of the hit path).  The reference caches (p, v) by position hash
                              * (utils/proxies.py:35-43); results are identical either way */
-    int32_t reserved0;
+    int32_t max_pending_evals; /* UCT_search's max_pending_evals (mcts.py:183): simulations of ONE tree in flight.  0 / 1 = the
+                             * sequential search (all parity paths, self-play); K > 1 = waves of up to K selections with
+                             * virtual loss, one batched evaluation per wave (dbaz_search / dbaz_search_timed only) */
 } dbaz_config;
 
 typedef struct {
@@ -152,6 +154,13 @@ int dbaz_set_positions(dbaz_engine *e, const int16_t *moves, const int32_t *offs
  *                       NULL = drawn on the device (Philox)
  * Blocks until every slot finished its reads.  Not for DBAZ_EVAL_EXTERNAL. */
 int dbaz_search(dbaz_engine *e, const int32_t *num_reads, const double *noise);
+/* the same with UCT_search's wall-clock cut-off (mcts.py:201-203,232-233; players.py:55-69 calls
+ * UCT_search(node, int(1e12), ..., time_limit)): reads that have not started when time_limit_s (<= 0: 120 s) has
+ * elapsed are dropped; the root expansion is never cut; the clock is read between waves */
+int dbaz_search_timed(dbaz_engine *e, const int32_t *num_reads, const double *noise, double time_limit_s);
+/* per-call max_pending_evals of a handle created with max_pending_evals = K > 1: 1 <= k <= K simulations in flight
+ * (k = 1 through the same kernels reproduces the sequential search bit for bit) */
+int dbaz_set_pending(dbaz_engine *e, int32_t k);
 /* external-evaluator form of the same call: begin, then loop
  *   dbaz_select -> (evaluate leaves on the host) -> dbaz_expand_backup  until *n_active == 0 */
 int dbaz_search_begin(dbaz_engine *e, const int32_t *num_reads, const double *noise);

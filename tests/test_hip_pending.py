@@ -1,0 +1,153 @@
+"""UCT_search with several pending evaluations on one tree (mcts.py:228-239; players.AZPlayer):
+k_select_multi / k_expand_backup_multi through the C ABI.  With one simulation in flight the kernels must reproduce the
+sequential search -- the reference's golden scripts and the oracle -- bit for bit; with K > 1 (our synchronous-wave
+semantics with counted virtual visits: parity unpinned, the reference's asyncio interleaving is not reproduced) the
+bookkeeping identities of mcts.py hold, results are deterministic, and the wall-clock cut-off works."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+_G = load_golden("mcts.npz")
+CASES = [str(c) for c in _G["cases"]]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_one_pending_equals_reference_golden(name):
+    from dotsboxesaz_amd.engine import Engine
+    g = _G
+    rows, cols, kind, c0, c1 = g[name + "_cfg"]
+    e = Engine(int(rows), int(cols), 2, mcts_num_read=800, evaluator="uniform" if kind == 1 else "formula", max_pending_evals=8)
+    e.set_pending(1)
+    st = list(g[name + "_start"])
+    e.set_positions([st, st])
+    for si, (op, a, b, c) in enumerate(g[name + "_script"]):
+        key = "%s_s%d_" % (name, si)
+        if op == 0:
+            e.set_search_params((c0, c1), (b, c))
+            e.search(int(a), None if b <= 0 else np.stack([g[key + "noise"]] * 2))
+            r = e.roots()
+            for s in (0, 1):
+                assert np.array_equal(r["visits"][s], g[key + "visits"]), key
+                assert np.array_equal(r["total_value"][s].view(np.uint32), g[key + "total_value"].view(np.uint32)), key
+                assert np.array_equal(r["priors"][s].view(np.uint64), g[key + "priors"].view(np.uint64)), key
+                assert list(r["stats"][s]) == list(g[key + "stats_i"]), key
+                assert r["q"][s].view(np.uint32) == g[key + "q"].view(np.uint32), key
+                assert r["root_nv"][s] == g[key + "root_nv"]
+        else:
+            e.advance(int(a), bool(b))
+    e.close()
+
+
+def _starts(d, n_slots, rng):
+    starts = []
+    for s in range(n_slots):
+        st, mv = O.new_state(d), []
+        for _ in range(rng.randint(0, max(1, d.A // 3))):
+            legal = np.nonzero(O.valid_moves(d, st))[0]
+            m = int(legal[rng.randint(len(legal))])
+            tmp = st.copy()
+            O.play_(d, tmp, m)
+            if O.get_result(tmp) is not None:
+                break
+            st = tmp
+            mv.append(m)
+        starts.append(mv)
+    return starts
+
+
+@pytest.mark.parametrize("rows,cols,n_slots,sims,K", [(3, 3, 32, 200, 8), (6, 6, 16, 500, 64), (6, 6, 4, 333, 5), (9, 9, 6, 300, 64)])
+def test_pending_waves_bookkeeping(rows, cols, n_slots, sims, K):
+    from dotsboxesaz_amd.engine import Engine
+    d = O.dims(rows, cols)
+    starts = _starts(d, n_slots, np.random.RandomState(K + sims))
+
+    def run():
+        e = Engine(rows, cols, n_slots, mcts_num_read=sims, evaluator="formula", max_pending_evals=K)
+        e.set_positions(starts)
+        e.search(sims)
+        r, c = e.roots(), e.counters()
+        e.advance(np.argmax(r["visits"], axis=1).astype(np.int32), True)
+        e.search(sims)
+        r2, c2 = e.roots(), e.counters()
+        e.close()
+        return r, c, r2, c2
+
+    r, c, r2, c2 = run()
+    # every read backs up through the root; the search that expanded the root visits no child (mcts.py:121-126,207-208)
+    assert (r["root_nv"] == sims + 1).all() and (r["visits"].sum(1) == sims).all()
+    assert c["expansions"] == n_slots * (sims + 1) and c["error_slots"] == 0
+    assert np.isfinite(r["total_value"]).all() and np.isfinite(r["q"]).all()
+    # a wave's simulations spread: at K >= 8 the most visited child of a fresh root holds well under all of the visits
+    assert (r["visits"].max(1) < sims).all()
+    # after the re-root the kept subtree arrives with its visits (tree_size); its root was expanded
+    assert (r2["stats"][:, 1] > 0).all()
+    # (reads of one wave that ended at the kept child while its evaluation was pending went no deeper: up to K of them)
+    below = r2["visits"].sum(1) - sims
+    assert (below <= r2["stats"][:, 1] - 1).all() and (below >= r2["stats"][:, 1] - K).all() and (r2["root_nv"] == sims).all()
+    assert c2["expansions"] == n_slots * (2 * sims + 1)
+    # evaluations + shared leaves (selected again while pending) + terminal leaves account for every read
+    assert c2["nn_evals"] + c2["cache_hits"] + c2["terminal_leaves"] == c2["expansions"]
+    # deterministic: a second handle reproduces every number
+    s, cs, s2, cs2 = run()
+    for k in ("visits", "total_value", "priors", "stats"):
+        assert np.array_equal(r[k], s[k]) and np.array_equal(r2[k], s2[k]), k
+    assert cs2 == c2 or all(cs2[k] == c2[k] for k in ("expansions", "nn_evals", "cache_hits", "terminal_leaves", "sum_path"))
+
+
+def test_pending_with_network_and_time_limit():
+    """AZPlayer's call: UCT_search(node, int(1e12), nn, cpuct, max_async_searches=64, (0, 0), time_limit): one 6x6 tree,
+    64 reads in flight, random-init ResNetZero on the device; stops on the clock, leaves a usable tree."""
+    import torch
+    from oracle import nn_ref
+    from dotsboxesaz_amd.engine import Engine
+    torch.manual_seed(0)
+    m = nn_ref.ResNetZeroRef(6, 6, 64, 4)
+    nn_ref.randomize_bn(m, 2)
+    e = Engine(6, 6, 1, mcts_num_read=800, evaluator="resnet", nn_precision=1, nodes_per_slot=400000, max_pending_evals=64)
+    e.load_state_dict(m.state_dict(), "resnet", 64, 4, 16, 8)
+    e.set_positions(None)
+    t0 = time.time()
+    e.search_timed(0.5, num_reads=2 ** 31 - 1)
+    dt = time.time() - t0
+    r, c = e.roots(), e.counters()
+    assert 0.45 < dt < 3.0
+    reads = int(r["root_nv"][0]) - 1
+    assert reads > 2000 and r["visits"][0].sum() == reads and c["expansions"] == reads + 1
+    assert c["nn_evals"] + c["cache_hits"] + c["terminal_leaves"] == c["expansions"]
+    print("single 6x6 tree, 64 pending, ResNetZero 4x64: %.0f reads/s" % (reads / dt))
+    mv = int(np.argmax(r["visits"][0]))
+    e.advance([mv], True)
+    e.search(100)
+    r2 = e.roots()
+    below = r2["visits"][0].sum() - 100
+    assert r2["root_nv"][0] == 100 and r2["stats"][0, 1] - 64 <= below <= r2["stats"][0, 1] - 1
+    e.close()
+
+
+def test_az_player_mirror_time_limited_move():
+    """players.AZPlayer request through the mirrors: create_root_uct_node(state, nn=model) + UCT_search(node, int(1e12),
+    ..., max_async_searches, (0, 0), time_limit) on the device."""
+    import torch
+    from dotsboxesaz_amd import nn as dnn
+    from dotsboxesaz_amd.game import BoxesState
+    from dotsboxesaz_amd.players import AZPlayer
+    BoxesState.init_static_fields(((3, 3),))
+    params = dnn.resnet_params(3, 3, 32, 2)
+    params["nn"]["model_class"] = dnn.ResNetZero
+    params["self_play"] = {"mcts": {"mcts_cpuct": (1.25, 19652), "max_async_searches": 16}}
+    torch.manual_seed(1)
+    player = AZPlayer(params, time_limit=0.3)
+    s = BoxesState()
+    for m in (0, 5, 17):
+        s.play_(m)
+    t0 = time.time()
+    move, policy, rate = player.get_move(s)
+    dt = time.time() - t0
+    assert move is not None and s.get_valid_moves()[move] and policy[move] == policy.max() > 0
+    assert policy.sum() > 500 and 0.25 < dt < 5.0 and rate > 1000
+    assert (policy[~np.asarray(s.get_valid_moves(), bool)] == 0).all()
