@@ -119,7 +119,10 @@ def make_engine(args, precision, rank, local_rank, torch, slots=None):
     if args.evaluator == "resnet":
         torch.manual_seed(0)
         model = dnn.ResNetZero(dnn.resnet_params(rows, cols, args.channels, args.blocks))
-        eng.load_state_dict(model.state_dict(), "resnet", **model.shape)
+        sd = model.state_dict()
+        if args.zero_weights:  # DVFS diagnosis only (MI355X_MICROARCH.md, give-back item 1): all-zero MFMA operands
+            sd = {k: (v * 0 if ("conv" in k or "fc" in k) else v) for k, v in sd.items()}
+        eng.load_state_dict(sd, "resnet", **model.shape)
     elif args.evaluator == "simplenn":
         torch.manual_seed(0)
         eng.load_state_dict(dnn.SimpleNN().state_dict(), "simplenn")
@@ -366,6 +369,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-side-run", action="store_true")
+    ap.add_argument("--zero-weights", action="store_true", help="diagnosis: all conv/fc weights zero (clock under load vs operand data)")
     ap.add_argument("--no-tt", action="store_true", help="switch the per-game transposition table off (kernel measurements)")
     ap.add_argument("--fresh-population", action="store_true",
                     help="skip the population preparation (staggered first searches + sims+64 untimed steps): every tree "

@@ -771,8 +771,10 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
     // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
     // 16x16x32: waves 0-3 own position tiles [0, NTA), waves 4-7 tiles [NTA, NTA+NTB)
     // 32x32x16: the wave pair (wave >> 1) owns tiles [(wave >> 1) * NTA, +NTA), one 32-cout tile each
+    //           (NTB > 0: the older wave half takes NTA tiles per wave, the younger NTB -- tools/ab_mf32.sh)
     const bool first = wave < 4;
-    const int tbase = MF ? (wave >> 1) * NTA : (first ? 0 : NTA);
+    const int tbase = MF ? (NTB > 0 ? (first ? ((wave >> 1) & 1) * NTA : 2 * NTA + ((wave >> 1) & 1) * NTB) : (wave >> 1) * NTA)
+                         : (first ? 0 : NTA);
     int vm[NTA];
 #pragma unroll
     for (int t = 0; t < NTA; t++) {
@@ -815,7 +817,10 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             const f32x4 *src = (l & 1) ? Y4 : X4;
             f32x4 *dst = (l & 1) ? X4 : Y4;
             const f32x4 *nxt = l + 1 < NL ? tw4 + (size_t)(l + 1) * wl : nullptr;
-            if constexpr (MF) {
+            if constexpr (MF && NTB > 0) {
+                if (first) conv_lds_h3_32<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
+                else conv_lds_h3_32<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
+            } else if constexpr (MF) {
                 conv_lds_h3_32<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
             } else {
                 if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
