@@ -156,8 +156,8 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
             dist.barrier()
 
     eng.step(warmup)
-    sync_all()
-    c0 = eng.counters()
+    c0 = eng.counters()  # (before the bracket: the GPU should idle as briefly as possible ahead of the timed steps -- after an
+    sync_all()           #  idle gap the chip needs ~25 launches to return to its sustained clock, profiles/r02_post_idle_ramp.txt)
     eng.timing_begin()
     t0 = time.perf_counter()
     eng.step(steps)
