@@ -129,22 +129,37 @@ def make_engine(args, precision, rank, local_rank, torch, slots=None):
     return eng
 
 
-def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, torch):
+def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, torch, population=None):
     """One timed region on this rank's GPU; returns the raw measurements.
 
-    Population (synthetic input, built before the W warm-up steps): slot i starts (i*37 mod 0.7E) uniformly random
-    legal plies into a game, and its FIRST search is cut to (i*61 mod sims)+1 reads; the engine then runs sims+64
-    untimed preparation steps, after which every slot is in its second or later search of a game -- a re-rooted tree
-    with the reused subtree, read counters spread uniformly over [0, sims) -- i.e. the steady state of a long
-    self-play run, which the K timed steps then sample (with fresh trees a 20-step window saw
-    path length 2.9 and no terminal leaves)."""
+    Population (synthetic input, built before the W warm-up steps; --population):
+      games   (default) slot i plays the first (i*37 mod game length) plies of a game with --quick-reads simulations per
+              move (real search, network, temperature, tree reuse -- only a smaller budget), then its first full search is
+              cut to (i*61 mod sims)+1 reads; after the untimed preparation steps every slot is somewhere inside a full
+              search of a mid-game move with a re-rooted, reused tree: the steady state of a long self-play run with
+              slot refill, on positions of the kind search-based play reaches;
+      random  the same with uniformly random legal plies instead of quick play (cheaper to build, but random play leaves
+              positions with more terminal leaves and transpositions than games have: 12.7 % / 38.6 % against the 5.3 % /
+              30.6 % measured over complete games);
+      fresh   round 1: random plies, empty trees (path length 2.9, no terminal leaves in a 20-step window)."""
     eng = make_engine(args, precision, rank, local_rank, torch)
-    span = max(1, int(0.7 * eng.E))
-    eng.selfplay_fastforward((np.arange(args.slots) * 37) % span)
     prep = 0
-    if not args.fresh_population:
+    population = population or args.population
+    if population == "games":
+        # slot i: the first (i*37 mod E_mean) plies of its game at args.quick_reads reads per move, then a first full search
+        # cut to (i*61 mod sims)+1 reads; E_mean = the mean length of a game (plies), so the slots sample a game's plies uniformly
+        span = max(1, int(args.game_plies or 0.97 * eng.E))
+        plies = (np.arange(args.slots) * 37) % span
+        eng.selfplay_quickplay(plies, args.quick_reads)
+        eng.selfplay_stagger((np.arange(args.slots) * 61) % max(1, args.sims) + 1)
+        prep = int(plies.max()) * (args.quick_reads + 2) + args.sims + 64
+    elif population == "random":
+        span = max(1, int(0.7 * eng.E))
+        eng.selfplay_fastforward((np.arange(args.slots) * 37) % span)
         eng.selfplay_stagger((np.arange(args.slots) * 61) % max(1, args.sims) + 1)
         prep = args.sims + 64
+    else:  # "fresh": round 1's population, every tree empty
+        eng.selfplay_fastforward((np.arange(args.slots) * 37) % max(1, int(0.7 * eng.E)))
     eng.selfplay_start(1 << 40, rank * (1 << 32))
     eng.step(prep)
 
@@ -371,9 +386,11 @@ def main():
     ap.add_argument("--no-f32-side-run", action="store_true")
     ap.add_argument("--zero-weights", action="store_true", help="diagnosis: all conv/fc weights zero (clock under load vs operand data)")
     ap.add_argument("--no-tt", action="store_true", help="switch the per-game transposition table off (kernel measurements)")
-    ap.add_argument("--fresh-population", action="store_true",
-                    help="skip the population preparation (staggered first searches + sims+64 untimed steps): every tree "
-                         "starts empty, as in round 1's bench")
+    ap.add_argument("--population", default="games", choices=["games", "random", "fresh"],
+                    help="how the slots' starting positions and trees are prepared before the warm-up (see run_engine)")
+    ap.add_argument("--fresh-population", action="store_true", help="same as --population fresh")
+    ap.add_argument("--quick-reads", type=int, default=48, help="--population games: simulations per move of the opening plies")
+    ap.add_argument("--game-plies", type=int, default=0, help="--population games: plies sampled (0 = 0.97 E, the mean game length)")
     ap.add_argument("--games-leg", type=int, default=-1,
                     help="complete games played (per rank) AFTER the timed steps for the directly measured games/s of the "
                          "metric; -1 = one game per slot (the BASELINE config's game count), 0 = skip")
@@ -393,6 +410,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.fresh_population:
+        args.population = "fresh"
     special = args.full_games > 0 or args.train_data > 0 or args.single_tree > 0
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not special:
@@ -425,7 +444,9 @@ def main():
     side = None
     if args.evaluator == "resnet" and args.precision >= 1 and not args.no_f32_side_run:
         st = max(20, args.steps // 6)
-        eng0, m0 = run_engine(args, 0, st, max(5, args.warmup // 5), rank, local_rank, world, dist, torch)
+        # (exact-f32 steps are 6x longer: the side run keeps the cheap population; it reports the tower's f32 efficiency)
+        eng0, m0 = run_engine(args, 0, st, max(5, args.warmup // 5), rank, local_rank, world, dist, torch,
+                              population="random" if args.population == "games" else None)
         eng0.close()
         side = (m0, st)
     # the second half of the metric, measured directly: complete games from the empty board on every rank's slots
@@ -466,8 +487,10 @@ def main():
         }
         # games/s: expansions/s divided by the measured mean expansions of a full game
         # (DESIGN.md "Measurement"; 6x6 @ 800 sims: 63.2k)
-        out["population"] = ("steady state: staggered first searches + %d untimed preparation steps" % m["prep_steps"]
-                             if m["prep_steps"] else "fresh trees")
+        out["population"] = {"games": "mid-game positions reached by quick play (%d reads per move), staggered full searches, %d "
+                                      "untimed preparation steps" % (args.quick_reads, m["prep_steps"]),
+                             "random": "uniformly random plies, staggered full searches, %d untimed preparation steps" % m["prep_steps"],
+                             "fresh": "uniformly random plies, fresh trees"}[args.population]
         if leg:
             out["games_per_sec"] = leg["value"]  # whole-job aggregate, measured on complete games
             out["games_leg"] = leg

@@ -21,7 +21,7 @@ SYMBOLS = [
     "dbaz_nn_configure", "dbaz_nn_select_model", "dbaz_nn_set_tensor", "dbaz_nn_commit", "dbaz_nn_predict",
     "dbaz_set_search_params", "dbaz_set_positions", "dbaz_search", "dbaz_search_timed", "dbaz_set_pending", "dbaz_search_begin", "dbaz_select", "dbaz_expand_backup",
     "dbaz_get_roots", "dbaz_get_root_states", "dbaz_advance",
-    "dbaz_selfplay_start", "dbaz_selfplay_script", "dbaz_selfplay_fastforward", "dbaz_selfplay_stagger", "dbaz_step", "dbaz_run",
+    "dbaz_selfplay_start", "dbaz_selfplay_script", "dbaz_selfplay_fastforward", "dbaz_selfplay_stagger", "dbaz_selfplay_quickplay", "dbaz_step", "dbaz_run",
     "dbaz_get_counters", "dbaz_timing_begin", "dbaz_timing_end", "dbaz_fetch_samples", "dbaz_replay_rows_dev",
     "dbaz_replay_rows_clear", "dbaz_dataset_select", "dbaz_dataset_begin", "dbaz_dataset_add_rows", "dbaz_dataset_finish", "dbaz_dataset_fetch", "dbaz_dataset_batch",
     "dbaz_symmetry_apply", "dbaz_symmetry_table",
@@ -109,6 +109,7 @@ def load():
     L.dbaz_selfplay_script.argtypes = [vp, i64, vp, i32, vp]
     L.dbaz_selfplay_fastforward.argtypes = [vp, vp]
     L.dbaz_selfplay_stagger.argtypes = [vp, vp]
+    L.dbaz_selfplay_quickplay.argtypes = [vp, vp, i32]
     L.dbaz_step.argtypes = [vp, i32]
     L.dbaz_run.argtypes = [vp, i64]
     L.dbaz_get_counters.argtypes = [vp, C.POINTER(Counters)]

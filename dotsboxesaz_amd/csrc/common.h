@@ -74,6 +74,7 @@ struct Slot {
     int32_t root;            // node index of the current root
     int32_t n_free;          // entries on the free stack (recycled node indices)
     int32_t pend_head, pend_tail; // ring of dropped nodes whose children have not been enumerated yet
+    int32_t quick_until;     // benchmark population: plies of the slot's FIRST game that are searched with SearchCfg.quick_reads
     int32_t wave_sims;       // K > 1 search: simulations selected in the current wave, waiting for expand/backup
     int32_t first_wave;      // K > 1 search: the first wave of a UCT_search call is min(K, A) wide (mcts.py:228-229)
 };
@@ -120,6 +121,7 @@ struct SearchCfg {
     int table_n;             // entries in pbc/sqrt tables
     int step;                // engine step counter of this launch
     int driver_concurrent;   // this k_select runs next to the driver pass of the same step (self-play stepping)
+    int quick_reads;         // read budget of the quick plies (dbaz_selfplay_quickplay)
     int pending;             // K > 1 search: width of a wave (<= TreeBufs.kmax), dbaz_set_pending
 };
 

@@ -53,7 +53,7 @@ struct dbaz_engine {
     std::vector<uint8_t> script_has_noise;
     int64_t script_first = -1;
     int n_script = 0;
-    std::vector<int32_t> ff_plies, ff_reads;
+    std::vector<int32_t> ff_plies, ff_reads, quick_plies;
     SlotSummary *d_sum = nullptr;
     bool selfplay = false;
     bool search_open = false;
@@ -923,6 +923,17 @@ extern "C" int dbaz_selfplay_stagger(dbaz_engine *e, const int32_t *first_reads)
     return DBAZ_OK;
 }
 
+extern "C" int dbaz_selfplay_quickplay(dbaz_engine *e, const int32_t *plies, int32_t reads)
+{
+    if (!e || !plies) return e ? set_error(e, DBAZ_EINVAL, "null argument") : DBAZ_EINVAL;
+    if (reads < 1) return set_error(e, DBAZ_EINVAL, "reads must be >= 1");
+    for (int i = 0; i < e->n_slots; i++)
+        if (plies[i] < 0) return set_error(e, DBAZ_EINVAL, "plies[%d] < 0", i);
+    e->quick_plies.assign(plies, plies + e->n_slots);
+    e->sc.quick_reads = reads;
+    return DBAZ_OK;
+}
+
 extern "C" int dbaz_selfplay_start(dbaz_engine *e, int64_t n_games, int64_t first_game_idx)
 {
     if (!e || n_games < 0) return e ? set_error(e, DBAZ_EINVAL, "bad argument") : DBAZ_EINVAL;
@@ -966,8 +977,10 @@ extern "C" int dbaz_selfplay_start(dbaz_engine *e, int64_t n_games, int64_t firs
         for (int i = 0; i < e->n_slots; i++) {
             hs[i].ff_plies = e->ff_plies.empty() ? 0 : e->ff_plies[i];
             hs[i].ff_reads = e->ff_reads.empty() ? 0 : e->ff_reads[i];
+            hs[i].quick_until = e->quick_plies.empty() ? 0 : e->quick_plies[i];
         }
         e->ff_reads.clear();
+        e->quick_plies.clear();
         HIP_CHECK_RET(e, hipMemcpy(B.slots, hs.data(), sizeof(Slot) * e->n_slots, hipMemcpyHostToDevice));
         e->ff_plies.clear();
     }

@@ -457,10 +457,17 @@ __device__ void begin_search(const Geo &g, const SearchCfg &cfg, const TreeBufs 
         num_reads = rule_num_reads(g, cfg, rm.st);
         // benchmark population (dbaz_selfplay_stagger): the slot's first search is cut short so that the slots'
         // move boundaries are spread over a whole search instead of all falling into the same step
-        const int ffr = S->ff_reads;
-        if (ffr > 0) {
-            num_reads = min(num_reads, ffr);
-            S->ff_reads = 0;
+        // (dbaz_selfplay_quickplay: the opening plies of the slot's first game are searched with a small budget -- a cheap way
+        // to a population of positions that search-based play reaches; the staggered budget applies to the first full search)
+        const int qu = S->quick_until;
+        if (qu > 0 && S->move_idx < qu) {
+            num_reads = min(num_reads, max(cfg.quick_reads, 1));
+        } else {
+            const int ffr = S->ff_reads;
+            if (ffr > 0) {
+                num_reads = min(num_reads, ffr);
+                S->ff_reads = 0;
+            }
         }
     }
     S->sims_left = num_reads;
@@ -1363,6 +1370,7 @@ __global__ void __launch_bounds__(WAVE) k_set_positions(Geo g, SearchCfg cfg, Tr
     }
     S->ff_plies = 0;
     S->ff_reads = 0;
+    S->quick_until = 0;
     fresh_game(g, cfg, B, slot, S, pool, slot, lane);
     init_node(pool, g, 0, st, -1, -1, 1, lane);
     if (lane == 0) {
@@ -1468,6 +1476,7 @@ __device__ void next_game_or_idle(const Geo &g, const SearchCfg &cfg, const Tree
         S->phase = PH_IDLE;
         return;
     }
+    S->quick_until = 0; // only a slot's first game has quick plies
     fresh_game(g, cfg, B, slot, S, pool, gidx, lane);
     start_move_search(g, cfg, B, slot, S, pool, ldsf, ldsd, lane);
 }

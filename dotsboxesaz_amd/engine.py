@@ -259,6 +259,12 @@ class Engine:
         assert fr.shape == (self.n_slots,)
         self._ck(self._L.dbaz_selfplay_stagger(self.h, _p(fr)))
 
+    def selfplay_quickplay(self, plies, reads):
+        """Benchmark population: the first plies[i] plies of slot i's first game use `reads` simulations per move."""
+        pl = np.ascontiguousarray(plies, np.int32)
+        assert pl.shape == (self.n_slots,)
+        self._ck(self._L.dbaz_selfplay_quickplay(self.h, _p(pl), int(reads)))
+
     def selfplay_start(self, n_games, first_game_idx=0):
         self._ck(self._L.dbaz_selfplay_start(self.h, int(n_games), int(first_game_idx)))
 

@@ -195,6 +195,11 @@ int dbaz_selfplay_fastforward(dbaz_engine *e, const int32_t *plies);
  * whole search instead of falling into the same steps.  Like dbaz_selfplay_fastforward it applies to the next
  * dbaz_selfplay_start only and is never used on the parity paths. */
 int dbaz_selfplay_stagger(dbaz_engine *e, const int32_t *first_reads);
+/* benchmark population, third knob: the first plies[i] plies of slot i's FIRST game are searched with `reads` simulations
+ * per move instead of mcts_num_read -- real search, network, temperature schedule and tree reuse, only cheaper -- so that
+ * the slots reach mid-game positions of the kind search-based play produces (uniformly random plies, the fastforward knob,
+ * give positions with more terminal leaves and transpositions than games do).  Applies to the next dbaz_selfplay_start. */
+int dbaz_selfplay_quickplay(dbaz_engine *e, const int32_t *plies, int32_t reads);
 int dbaz_step(dbaz_engine *e, int32_t k);             /* k simulation steps, asynchronous */
 /* until all games are finished, max_steps (if > 0) are done, or every remaining slot is
  * blocked on a full output buffer (counters.blocked_slots == active_slots: fetch and call again) */

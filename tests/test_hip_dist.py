@@ -67,7 +67,7 @@ def test_bench_under_torch_distributed_run():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["replay_allgather"]["rows"] == 256 * 8
+    assert d["value"] > 0 and d["replay_allgather"]["rows"] >= 256 * 8  # the synthetic shard, or the finished rows if more
     assert np.isfinite(d["roofline"]["frac"])
 
 

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$1
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 bench.py --gpus 1 --steps 60 --warmup 10 --slots $2 --precision $3 --fresh-population --no-tt --no-cpu-baseline --no-f32-side-run --games-leg 0 > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 bench.py --gpus 1 --steps 60 --warmup 10 --slots $2 --precision $3 --population fresh --no-tt --no-cpu-baseline --no-f32-side-run --games-leg 0 > $OUT/bench.json 2> $OUT/err.txt
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)
