@@ -579,7 +579,6 @@ static int sim_wave(dbaz_engine *e)
     const bool use_nn = e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN;
     e->sc.step = (int)(e->steps & 0x3FFFFFFF) + 1;
     e->sc.driver_concurrent = 0;
-    if (use_nn) HIP_CHECK_RET(e, hipMemsetAsync(e->B.n_eval, 0, 8, s));
     tree_launch_select_multi(s, e->g, e->sc, e->B, e->n_slots);
     if (use_nn) {
         nn_forward(e->nns[0], s, e->B.feat_m, e->B.list_m, e->B.n_eval, e->n_slots * e->B.kmax, e->B.evalP_m, e->B.evalV_m, e->g.AS, nullptr, nullptr);
@@ -612,8 +611,7 @@ static int sim_step(dbaz_engine *e, bool with_driver)
         tree_launch_advance_auto(e->stream2, e->g, e->sc, e->B, e->n_slots);
         HIP_CHECK_RET(e, hipEventRecord(e->ev_join, e->stream2));
     }
-    if (use_nn || use_nn2) HIP_CHECK_RET(e, hipMemsetAsync(e->B.n_eval, 0, 8, s));
-    tree_launch_select(s, e->g, e->sc, e->B, e->n_slots);
+    tree_launch_select(s, e->g, e->sc, e->B, e->n_slots); // (the lists' counters were zeroed by the previous k_expand_backup)
     if (with_driver) HIP_CHECK_RET(e, hipStreamWaitEvent(s, e->ev_join, 0));
     if (use_nn) {
         hipEvent_t a = nullptr, b = nullptr;

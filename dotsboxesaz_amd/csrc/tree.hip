@@ -108,7 +108,9 @@ __device__ void init_node(uint32_t *pool, const Geo &g, int idx, const GState &s
 // the tree plus one move's worth of garbage.  (Round 1 compacted the kept subtree in place: 2.5-4 MB
 // moved by one wave for 0.4-2 ms per move, on a CU the network's workgroups then could not use.)
 // ------------------------------------------------------------------------------------
+#ifndef GC_PER_STEP
 #define GC_PER_STEP 2
+#endif
 struct PoolState { int n_nodes, n_free, head, tail; };
 
 __device__ __forceinline__ PoolState pool_load(const Slot *S)
@@ -1043,6 +1045,7 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup_multi(Geo g, SearchCfg c
     __shared__ float ldsf[DBAZ_MAX_A];
     __shared__ double ldsd[DBAZ_MAX_A];
     const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot == 0 && lane == 0) { B.n_eval[0] = 0; B.n_eval[1] = 0; }
     Slot *S = B.slots + slot;
     const int phase = S->phase;
     if (phase != PH_EXPAND_ROOT && phase != PH_SIMS) return;
@@ -1128,6 +1131,9 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
     __shared__ float ldsf[DBAZ_MAX_A];
     __shared__ double ldsd[DBAZ_MAX_A];
     const int slot = blockIdx.x, lane = threadIdx.x;
+    // the step's last kernel resets the per-step counters for the next one (the evaluation lists were consumed by the network
+    // launches before it, the driver list by the pass joined before them): no memset launches between the kernels
+    if (slot == 0 && lane == 0) { B.n_eval[0] = 0; B.n_eval[1] = 0; B.drv_count[0] = 0; }
     Slot *S = B.slots + slot;
     const int phase = S->phase;
     if (phase != PH_EXPAND_ROOT && phase != PH_SIMS)
@@ -1869,7 +1875,6 @@ void tree_launch_selfplay_start(hipStream_t s, const Geo &g, const SearchCfg &c,
 }
 void tree_launch_advance_auto(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots)
 {
-    (void)hipMemsetAsync(B.drv_count, 0, 4, s);
     hipLaunchKernelGGL(k_driver_scan, dim3((n_slots + 255) / 256), dim3(256), 0, s, c, B, n_slots);
     hipLaunchKernelGGL(k_advance_auto, dim3(n_slots < 1024 ? n_slots : 1024), dim3(WAVE), 0, s, g, c, B);
 }
