@@ -562,7 +562,9 @@ __device__ __forceinline__ void load_rows(NodeRows<NPL> &r, uint32_t *pool, cons
     }
 }
 
+#ifndef SELECT_WAVES
 #define SELECT_WAVES 16 // games per workgroup (one wave each)
+#endif
 // returns the model (0 / 1) whose network must evaluate this game's leaf, or -1
 template <int NPL>
 __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &B, int slot, int lane)

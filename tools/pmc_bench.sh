@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 PMC passes (one counter group per run, --kernel-trace only beside --pmc) over a short bench.py run.
+#   tools/pmc_bench.sh <tag> <bench.py flags...>   -> gpurun_out/pmc_<tag>/pass*/...
+# then: python tools/pmc_summary.py gpurun_out/pmc_<tag> profiles/<name>.json
+cd /tmp && export TMPDIR=/tmp
+TAG=$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pass$i -o p -- python3 bench.py "$@" > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed"
+  echo "pass $i ($grp) done"
+done

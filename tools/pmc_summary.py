@@ -17,7 +17,8 @@ import sys
 def main(src, dst):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
-    for f in sorted(glob.glob(src + "/*/*/*_counter_collection.csv")):
+    files = sorted(glob.glob(src + "/*/*/*_counter_collection.csv")) + sorted(glob.glob(src + "/*/*_counter_collection.csv"))
+    for f in files:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
