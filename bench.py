@@ -356,7 +356,7 @@ def tower_roofline(args, m, steps, precision):
     peak = F32_MFMA_PEAK_TFLOPS if precision == 0 else F16_MFMA_PEAK_TFLOPS / 3.0
     return {"bound": "mfma",
             "kernel": "k_tower<%d,*,%s> (conv0 + 2*%d conv3x3 + head 1x1 convs fused, LDS-resident)"
-                      % (args.channels, {0: "f32", 1: "f16x3 on 16x16x32", 2: "f16x3 on 32x32x16"}[precision], args.blocks),
+                      % (args.channels, {0: "f32", 1: "f16x3 on 16x16x32 (two cout tiles per wave at 64 channels)", 2: "f16x3 on 32x32x16", 3: "f16x3 on 16x16x32, two cout tiles per wave", 4: "f16x3 on 16x16x32, one cout tile per wave"}[precision], args.blocks),
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "peak_note": ("dense f32 MFMA" if precision == 0 else
                           "dense f16 MFMA / 3 (three f16 MFMAs per f32-grade product); algorithmic flops counted once"),
@@ -377,7 +377,7 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "simplenn", "formula", "uniform"])
-    ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2],
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2, 3, 4],
                     help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default); 2 = the same arithmetic on "
                          "the 32x32x16 MFMA tiling (DESIGN.md 5.1: measured, not faster)")
     ap.add_argument("--nodes-per-slot", type=int, default=0, help="tree node pool per game (0 = engine default 10*(sims+2))")

@@ -84,6 +84,9 @@ struct NNState {
     // 16x16 kernels, which remain in use for the exact-f32 fallback launch
     int want_mf32 = 0, mf32 = 0, S_mf = 0, NT2 = 0, S_mf_tail = 0;
     size_t conv_lds_mf = 0;
+    // f16x3 on 16x16x32 with two cout tiles per wave (k_tower<64, NT, 0, 1, 2>, 64 channels): 4 tile groups of NT_c2 tiles
+    int want_c2 = 0, c2 = 0, S_c2 = 0, NT_c2 = 0, S_c2_tail[3] = {0, 0, 0}; // tails: 1 / 2 / 3 tiles per wave
+    size_t conv_lds_c2 = 0;
 };
 
 // ------------------------------------------------------------------------------------
@@ -374,6 +377,169 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
 }
 
 // ------------------------------------------------------------------------------------
+// conv_lds_h3 with TWO 16-cout tiles per wave (MF = 2): a wave owns couts [32 (wave & 1), +32) and NTT position tiles of
+// the tile group wave >> 1, so every activation fragment it reads from LDS feeds 6 MFMAs instead of 3 -- half the LDS read
+// bytes per FLOP, fewer issue slots -- at the price of twice the weight stream per wave (four fragments per K-step).
+// The kernel is power-bound on real data (bench --zero-weights): not re-reading every other activation fragment
+// (timing experiment, wrong results) bought 6 %.
+// ------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void wpre_load_c2(WPre (&pre)[2], const f32x4 *wpk_layer, int wave, int lane)
+{
+    constexpr int N = 9 * (C / 32);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const f32x4 *wb = wpk_layer + (size_t)((wave & 1) * 2 + c) * N * 2 * 64 + lane;
+        pre[c].h0 = wb[0];
+        pre[c].l0 = wb[64];
+        pre[c].h1 = wb[128];
+        pre[c].l1 = wb[192];
+    }
+}
+
+template <int C, int NTT>
+__device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
+                                               const float *__restrict__ bias, float oscale, const int *vm, int rowbase,
+                                               int zbase, int W, int R, int wave, int lane, int residual, bool &ovf_out, int tbase,
+                                               WPre (&pre)[2], const f32x4 *next_wpk, unsigned long long *stamps = nullptr)
+{
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)stamps;
+    static_assert(C == 64, "two cout tiles per wave x two wave parities = 64 channels");
+    constexpr int S4 = (C + 8) / 4;  // 16-byte units per LDS row
+    constexpr int KS = C / 32;       // K=32 steps per tap
+    constexpr int LO = C / 8;        // unit offset of the lo halves inside a row
+    constexpr int N = 9 * KS;        // pipeline steps
+    const int jrow = lane & 15, gq = lane >> 4;
+    const int ct0 = (wave & 1) * 2;
+    f32x4 acc[2][NTT];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int t = 0; t < NTT; t++) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 *wb0 = wpk + (size_t)ct0 * N * 2 * 64 + lane;       // packed [ct][step][hi|lo][lane] 16-byte fragments
+    const f32x4 *wb1 = wb0 + (size_t)N * 2 * 64;
+    u128h a_h[2][3], a_l[2][3];
+    u128h bh[NTT], bl[NTT];
+    const char *sb = reinterpret_cast<const char *>(src4);
+    int ab[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; t++)
+        ab[t] = ((vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4) * 16;
+    STAMP(t0);
+#pragma unroll
+    for (int c = 0; c < 2; c++) { a_h[c][0].f = pre[c].h0; a_l[c][0].f = pre[c].l0; a_h[c][1].f = pre[c].h1; a_l[c][1].f = pre[c].l1; }
+#pragma unroll
+    for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4);
+#pragma unroll
+    for (int t = 0; t < NTT; t++) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + LO * 16);
+    STAMP(t1);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int cur = i % 3, nxt = (i + 2) % 3;
+        const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
+        if (i + 2 < N) {
+            a_h[0][nxt].f = wb0[(size_t)(i + 2) * 128];
+            a_l[0][nxt].f = wb0[(size_t)(i + 2) * 128 + 64];
+            a_h[1][nxt].f = wb1[(size_t)(i + 2) * 128];
+            a_l[1][nxt].f = wb1[(size_t)(i + 2) * 128 + 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // hi*hi for both cout tiles (the next tap's addresses are computed in their shadow)
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[0][cur].h, bh[t].h, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[1][cur].h, bh[t].h, acc[1][t], 0, 0, 0);
+        }
+        if (ni < N && nks == 0) {
+            const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
+            const int zt = zbase + ((rowbase + off) & 15);
+#pragma unroll
+            for (int t = 0; t < NTT; t++) ab[t] = (((vm[t] >> ntap) & 1) ? rowbase + off : zt - t * 16 * S4) * 16;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // lo*hi; bh[t] is dead after its second MFMA -> reload it for the next step right there
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[0][cur].h, bh[t].h, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[1][cur].h, bh[t].h, acc[1][t], 0, 0, 0);
+            if (ni < N) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // hi*lo; same for bl[t]
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[0][cur].h, bl[t].h, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[1][cur].h, bl[t].h, acc[1][t], 0, 0, 0);
+            if (ni < N) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64 + LO * 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    STAMP(t2);
+    f32x4 bv[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        bv[c] = *reinterpret_cast<const f32x4 *>(bias + (ct0 + c) * 16 + gq * 4);
+        asm volatile("" ::"v"(bv[c]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (next_wpk) wpre_load_c2<C>(pre, next_wpk, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue (as conv_lds_h3): lane holds couts (ct0 + c) * 16 + 4 gq .. +3 of position row (tbase + t) * 16 + jrow
+    _Float16 *dsth = reinterpret_cast<_Float16 *>(dst4);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    float vmax = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        u32x2 rh[NTT], rl[NTT];
+        if (residual) {
+#pragma unroll
+            for (int t = 0; t < NTT; t++) {
+                const int row = min((tbase + t) * 16 + jrow, R - 1);
+                const _Float16 *ph = dsth + (size_t)row * (S4 * 8) + (ct0 + c) * 16 + gq * 4;
+                rh[t] = *reinterpret_cast<const u32x2 *>(ph);
+                rl[t] = *reinterpret_cast<const u32x2 *>(ph + C);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            const int row = (tbase + t) * 16 + jrow;
+            f32x4 v = acc[c][t] * oscale + bv[c];
+            if (residual) {
+                union { unsigned int u; h2v h; } c0, c1, d0, d1;
+                c0.u = rh[t][0]; c1.u = rh[t][1]; d0.u = rl[t][0]; d1.u = rl[t][1];
+                v[0] += (float)c0.h[0] + (float)d0.h[0];
+                v[1] += (float)c0.h[1] + (float)d0.h[1];
+                v[2] += (float)c1.h[0] + (float)d1.h[0];
+                v[3] += (float)c1.h[1] + (float)d1.h[1];
+            }
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            vmax = fmaxf(vmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            union { h2v h[2]; u32x2 u; } oh, ol;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const f2v x = {v[2 * q], v[2 * q + 1]};
+                const h2v h = __builtin_convertvector(x, h2v);
+                oh.h[q] = h;
+                ol.h[q] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
+            }
+            if (row < R) {
+                _Float16 *ph = dsth + (size_t)row * (S4 * 8) + (ct0 + c) * 16 + gq * 4;
+                *reinterpret_cast<u32x2 *>(ph) = oh.u;
+                *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
+            }
+        }
+    }
+    ovf_out |= vmax > F16_GUARD;
+    STAMP(t3);
+#ifdef DBAZ_STAMP
+    if (stamps) { stamps[0] += t1 - t0; stamps[1] += t2 - t1; stamps[2] += t3 - t2; }
+#endif
+}
+
+// ------------------------------------------------------------------------------------
 // The same f16x3 layer on v_mfma_f32_32x32x16_f16 (MF = 1).  Output tile = 32 couts x 32 positions: a wave owns one
 // 32-cout tile (wave & 1) and NTT position tiles of 32 rows (tile group wave >> 1); per K=16 step it needs ONE weight
 // fragment pair for 3 * NTT MFMAs of 32 cycles each, and every activation fragment feeds twice the MACs of the 16x16x32
@@ -606,8 +772,10 @@ struct TowerArgs {
 template <int C, int NTA, int NTB, int PREC, int MF>
 __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, float *lds, const int S, const int s0, const int ns)
 {
-    static_assert(MF == 0 || PREC == 1, "the 32x32x16 tiling exists for the f16x3 mode only");
-    constexpr int STRIDE = MF ? C + 4 : C + 8; // dwords per LDS row (see conv_lds_h3_32 for the 32x32x16 tiling's choice)
+    static_assert(MF == 0 || PREC == 1, "the alternative tilings exist for the f16x3 mode only");
+    // MF: 0 = 16x16x32, a wave = one cout tile x half of the position tiles; 1 = 32x32x16; 2 = 16x16x32, a wave = two cout
+    // tiles x a quarter of the position tiles (conv_lds_h3_c2)
+    constexpr int STRIDE = MF == 1 ? C + 4 : C + 8; // dwords per LDS row (see conv_lds_h3_32 for the 32x32x16 tiling's choice)
     constexpr int S4 = STRIDE / 4;
     const int HW = g.HW, W = g.W, H = g.H;
     const int R = ns * HW;           // valid rows in this workgroup
@@ -766,8 +934,8 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
     __syncthreads();
     // position-tile rows / lane map of the layer MFMA: 16x16x32 (row = lane & 15, k quarter = lane >> 4) or
     // 32x32x16 (row = lane & 31, k half = lane >> 5)
-    constexpr int TR = MF ? 32 : 16;
-    const int jrow = lane & (TR - 1), gq = MF ? (lane >> 5) : (lane >> 4);
+    constexpr int TR = MF == 1 ? 32 : 16;
+    const int jrow = lane & (TR - 1), gq = MF == 1 ? (lane >> 5) : (lane >> 4);
     // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
     // 16x16x32: waves 0-3 own position tiles [0, NTA), waves 4-7 tiles [NTA, NTA+NTB)
     // 32x32x16: the wave pair (wave >> 1) owns tiles [(wave >> 1) * NTA, +NTA), one 32-cout tile each
@@ -804,8 +972,11 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         const size_t wl = (size_t)C * C * 9 * 2 * 2 / 16; // 16-byte units per layer (hi + lo halves)
         const int NL = 2 * a.nblocks;
         WPre pre;
+        WPre pre2[2];
+        (void)pre2;
         if (NL > 0) {
-            if constexpr (MF) wpre_load32<C>(pre, tw4, wave, lane);
+            if constexpr (MF == 2) wpre_load_c2<C>(pre2, tw4, wave, lane);
+            else if constexpr (MF == 1) wpre_load32<C>(pre, tw4, wave, lane);
             else wpre_load<C>(pre, tw4, wave, lane);
         }
         unsigned long long stamps[4] = {0, 0, 0, 0};
@@ -817,7 +988,9 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             const f32x4 *src = (l & 1) ? Y4 : X4;
             f32x4 *dst = (l & 1) ? X4 : Y4;
             const f32x4 *nxt = l + 1 < NL ? tw4 + (size_t)(l + 1) * wl : nullptr;
-            if constexpr (MF && NTB > 0) {
+            if constexpr (MF == 2) {
+                conv_lds_h3_c2<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre2, nxt, stamps);
+            } else if constexpr (MF && NTB > 0) {
                 if (first) conv_lds_h3_32<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
                 else conv_lds_h3_32<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
             } else if constexpr (MF) {
@@ -1353,6 +1526,10 @@ NNState *nn_create(const Geo &g, int max_batch, int precision)
     nn->max_batch = max_batch;
     nn->precision = precision == 2 ? 1 : precision; // 2 = the f16x3 arithmetic of 1 on the 32x32x16 MFMA tiling
     nn->want_mf32 = precision == 2 || getenv("DBAZ_MF32") != nullptr;
+    // 1 = f16x3 on the default tiling (two cout tiles per wave for 64-channel networks, one otherwise), 3 = the former and
+    // 4 = the latter explicitly (A/B measurements; the three give bit-identical results)
+    nn->want_c2 = precision == 1 || precision == 3;
+    if (precision == 3 || precision == 4) nn->precision = 1;
     return nn;
 }
 
@@ -1392,6 +1569,7 @@ int nn_configure(NNState *nn, int kind, int channels, int blocks, int head_chann
     if (nn->precision == 1 && cp < 32) cp = 32; // K = 32 per f16 MFMA step
     nn->kind = kind; nn->C = cp; nn->Craw = channels; nn->blocks = blocks; nn->hc = head_channels; nn->vf = value_fc;
     nn->mf32 = (nn->precision == 1 && nn->want_mf32 && (cp == 64 || cp == 128)) ? 1 : 0; // other widths stay on 16x16x32
+    nn->c2 = (nn->precision == 1 && nn->want_c2 && !nn->mf32 && cp == 64) ? 1 : 0;
     return DBAZ_OK;
 }
 
@@ -1538,6 +1716,20 @@ static hipError_t tower_inst_mf(NNState *nn, hipStream_t s, const TowerArgs &ta,
         (void)nn; (void)s; (void)ta; (void)nt2; (void)grid; (void)attr_only;
         return hipErrorInvalidValue;
     }
+}
+// two cout tiles per wave (C = 64): nt position tiles per wave, 4 tile groups
+static hipError_t tower_dispatch_c2(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt, int grid, bool attr_only)
+{
+#define C2_CASE(NT)                                                                                                                   \
+    case NT:                                                                                                                          \
+        if (attr_only) return hipFuncSetAttribute((const void *)k_tower<64, NT, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds_c2); \
+        hipLaunchKernelGGL((k_tower<64, NT, 0, 1, 2>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds_c2, s, nn->g, ta);                \
+        return hipSuccess;
+    switch (nt) {
+        C2_CASE(1) C2_CASE(2) C2_CASE(3) C2_CASE(4)
+    default: return hipErrorInvalidValue;
+    }
+#undef C2_CASE
 }
 static hipError_t tower_dispatch_mf(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt2, int grid, bool attr_only)
 {
@@ -1938,7 +2130,29 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     } else {
         nn->mf32 = 0;
     }
+    if (nn->c2 && C == 64) {
+        int Sc = MAXROWS / HW;
+        if (Sc > 16) Sc = 16;
+        while (Sc > 1 && lds_bytes(Sc) > lds_budget) Sc--;
+        nn->S_c2 = Sc;
+        nn->NT_c2 = ((Sc * HW + 15) / 16 + 3) / 4;           // tiles per wave (4 groups)
+        nn->conv_lds_c2 = lds_bytes(Sc);
+        // tail launches (one round of smaller, faster workgroups for the samples behind the last full round): 1, 2, 3
+        // tiles per wave; a variant is dropped when it holds no more samples than the next smaller one
+        int prev = 0;
+        for (int k = 0; k < 3; k++) {
+            int sk = (k + 1) < nn->NT_c2 ? std::min((k + 1) * 64 / HW, Sc - 1) : 0;
+            if (sk <= prev) sk = 0; else prev = sk;
+            nn->S_c2_tail[k] = sk;
+        }
+        if (nn->NT_c2 < 1 || nn->NT_c2 > 4) nn->c2 = 0;
+    } else {
+        nn->c2 = 0;
+    }
     hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true);
+    if (he == hipSuccess && nn->c2) he = tower_dispatch_c2(nn, nullptr, TowerArgs(), nn->NT_c2, 0, true);
+    for (int k = 0; k < 3; k++)
+        if (he == hipSuccess && nn->c2 && nn->S_c2_tail[k]) he = tower_dispatch_c2(nn, nullptr, TowerArgs(), k + 1, 0, true);
     if (he == hipSuccess && nn->mf32) he = tower_dispatch_mf(nn, nullptr, TowerArgs(), 2, 0, true);
     if (he == hipSuccess && nn->mf32) he = tower_dispatch_mf(nn, nullptr, TowerArgs(), 1, 0, true);
     if (he == hipSuccess && nn->tw32) he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true, 0);
@@ -1989,7 +2203,16 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.S_big = nn->S_big; ta.cus = nn->cus;
     ta.role = 0; ta.S = nn->S;
-    if (nn->mf32) {
+    if (nn->c2) {
+        // two cout tiles per wave (default for 64 channels): main launch + up to three tail launches, as below
+        ta.S_main = ta.S = nn->S_c2; ta.S_small = nn->S_c2_tail[0]; ta.S_mid = nn->S_c2_tail[1]; ta.S_big = nn->S_c2_tail[2];
+        (void)tower_dispatch_c2(nn, s, ta, nn->NT_c2, (max_n + nn->S_c2 - 1) / nn->S_c2, false);
+        for (int k = 0; k < 3; k++)
+            if (nn->S_c2_tail[k] > 0) {
+                ta.role = k + 1; ta.S = nn->S_c2_tail[k];
+                (void)tower_dispatch_c2(nn, s, ta, k + 1, nn->cus, false);
+            }
+    } else if (nn->mf32) {
         // 32x32x16 tiling: main launch + one tail launch of half-size workgroups (same split rule, derived from n on the device)
         ta.S_main = ta.S = nn->S_mf; ta.S_small = nn->S_mf_tail; ta.S_mid = ta.S_big = 0;
         (void)tower_dispatch_mf(nn, s, ta, nn->NT2, (max_n + nn->S_mf - 1) / nn->S_mf, false);

@@ -69,7 +69,8 @@ typedef struct {
     int32_t nn_precision;   /* 0 = exact f32 MFMA; 1 = f16x3 split MFMA (f32-grade; an evaluation whose activations leave
                              * f16's range is redone in exact f32 on the device, counters.f32_fallback_evals);
                              * 2 = the arithmetic of 1 on the 32x32x16 MFMA tiling (64- and 128-channel ResNetZero; other
-                             * networks run as 1) */
+                             * networks run as 1); 3 / 4 = 1 with the tiling of the layer kernel fixed (3: two cout tiles
+                             * per wave, 64 channels; 4: one) -- 1 picks between them, results are bit-identical */
     int32_t match_play;     /* two-model match play (self_play.compute_elo, :309-344): the evaluator of a move's
                                search is model (root.to_play XOR game_idx&1) */
     int32_t evaluator2;     /* DBAZ_EVAL_* of model 1 (match play) */

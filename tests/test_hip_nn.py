@@ -104,7 +104,7 @@ def test_predict_before_commit_is_an_error():
     e.close()
 
 
-@pytest.mark.parametrize("precision", [1, 2])
+@pytest.mark.parametrize("precision", [1, 2, 4])
 @pytest.mark.parametrize("rows,cols,ch,nb,n", [(6, 6, 64, 20, 64), (3, 3, 64, 20, 40), (9, 9, 64, 20, 10), (6, 6, 64, 3, 5),
                                                (4, 2, 32, 2, 50), (6, 6, 128, 2, 19), (2, 3, 8, 1, 12), (6, 6, 64, 2, 1500),
                                                (5, 3, 64, 2, 700)])
@@ -115,7 +115,7 @@ def test_f16x3_split_precision_mode(rows, cols, ch, nb, n, precision):
     torch.manual_seed(rows * 31 + cols + ch + n)
     m = nn_ref.ResNetZeroRef(rows, cols, ch, nb)
     nn_ref.randomize_bn(m, 5)
-    e = engine_for(rows, cols, m, n_slots=max(128, n), precision=precision)  # 2: the same arithmetic on 32x32x16 MFMA tiles
+    e = engine_for(rows, cols, m, n_slots=max(128, n), precision=precision)  # 2 / 3: the same arithmetic on other MFMA tilings
     e0 = engine_for(rows, cols, m, n_slots=max(128, n), precision=0)
     rng = np.random.RandomState(n)
     X = rng.randint(0, 2, size=(n, 3, rows + 1, cols + 1)).astype(np.float32)
@@ -127,6 +127,11 @@ def test_f16x3_split_precision_mode(rows, cols, ch, nb, n, precision):
     err0 = max(np.abs(p0 - pr).max(), np.abs(v0 - vr).max())
     print("f16x3 max abs err %.3g (exact-f32 MFMA path: %.3g)" % (err, err0))
     assert err < 2e-5, err
+    if precision == 4:  # the two 16x16x32 tilings accumulate in the same order: bit-identical
+        e3 = engine_for(rows, cols, m, n_slots=max(128, n), precision=3)
+        p3, v3 = e3.predict(X)
+        assert np.array_equal(p3, p) and np.array_equal(v3, v)
+        e3.close()
     assert np.allclose(p.sum(1), 1.0, atol=1e-5)
     e.close()
     e0.close()
@@ -159,7 +164,7 @@ def test_f16x3_range_overflow_falls_back_to_exact_f32():
     pr, vr = nn_ref.predict_sync(m, X)
     assert np.isfinite(p).all() and np.abs(p - pr).max() < TOL and np.abs(v - vr).max() < TOL
     c = e.counters()
-    assert 37 <= c["f32_fallback_evals"] <= 40  # every sample (in whole workgroups of 4)
+    assert 37 <= c["f32_fallback_evals"] <= 40  # every sample (in whole workgroups)
     e.close()
     # play continues: complete self-play games with this network, fallbacks counted, no error
     from dotsboxesaz_amd.engine import Engine
@@ -189,7 +194,7 @@ def test_f16x3_fallback_only_touches_the_overflowing_samples():
     pr, vr = nn_ref.predict_sync(m, X)
     assert np.abs(p - pr).max() < TOL and np.abs(v - vr).max() < TOL
     c = e.counters()
-    assert 2 <= c["f32_fallback_evals"] <= 8
+    assert 2 <= c["f32_fallback_evals"] <= 20  # whole workgroups: the flagged 5-sample groups, redone in 4-sample groups
     e.predict(X[100:400])
     assert e.counters()["f32_fallback_evals"] == c["f32_fallback_evals"]
     e.close()
