@@ -12,7 +12,7 @@ _lib.LIB_PATH = "build/stamp/libdbaz_hip.so"
 from dotsboxesaz_amd.engine import Engine
 from dotsboxesaz_amd import nn as dnn
 import os
-e = Engine(6, 6, 8192, evaluator="resnet", nn_precision=2 if os.environ.get("DBAZ_MF32") else 1)
+e = Engine(6, 6, 8192, evaluator="resnet", nn_precision=2 if os.environ.get("DBAZ_MF32") else (4 if os.environ.get("DBAZ_CLASSIC") else 1))
 torch.manual_seed(0)
 m = dnn.ResNetZero(dnn.resnet_params(6, 6))
 e.load_state_dict(m.state_dict(), "resnet", **m.shape)
@@ -38,8 +38,10 @@ for i, nme in enumerate(names):
 import os
 if os.environ.get("DBAZ_MF32"):
     print("32x32x16 tiling, 5 samples per workgroup; per layer: total %.0f, main %.0f (MFMA floor per wave: 36 steps x 6 MFMAs x 32 = %d; per SIMD twice that)" % (tot.mean() / 40, o[..., 1].mean() / 40, 36 * 6 * 32))
+elif os.environ.get("DBAZ_CLASSIC"):
+    print("16x16x32, one cout tile per wave, 4 samples per workgroup; per layer: total %.0f, main %.0f (MFMA floor 7 tiles: %d, 6 tiles: %d; per SIMD their sum)" % (tot.mean() / 40, o[..., 1].mean() / 40, 18 * 21 * 16, 18 * 18 * 16))
 else:
-    print("per layer: total %.0f, main %.0f (MFMA floor 7 tiles: %d, 6 tiles: %d)" % (tot.mean() / 40, o[..., 1].mean() / 40, 18 * 21 * 16, 18 * 18 * 16))
+    print("16x16x32, two cout tiles per wave, 5 samples per workgroup; per layer: total %.0f, main %.0f (MFMA floor per wave: 18 steps x 24 MFMAs x 16 = %d; per SIMD twice that)" % (tot.mean() / 40, o[..., 1].mean() / 40, 18 * 24 * 16))
 for w in range(8):
     print("wave", w, ["%.0f" % (o[:, w, i].mean() / 40) for i in range(5)])
 whole = o[..., 7].mean()
