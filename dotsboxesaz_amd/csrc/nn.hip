@@ -85,7 +85,7 @@ struct NNState {
     int want_mf32 = 0, mf32 = 0, S_mf = 0, NT2 = 0, S_mf_tail = 0;
     size_t conv_lds_mf = 0;
     // f16x3 on 16x16x32 with two cout tiles per wave (k_tower<64, NT, 0, 1, 2>, 64 channels): 4 tile groups of NT_c2 tiles
-    int want_c2 = 0, c2 = 0, S_c2 = 0, NT_c2 = 0, S_c2_tail[3] = {0, 0, 0}; // tails: 1 / 2 / 3 tiles per wave
+    int want_c2 = 0, c2 = 0, S_c2 = 0, NT_c2 = 0; // (its tail launches are the one-cout-tile kernels below)
     size_t conv_lds_c2 = 0;
 };
 
@@ -764,7 +764,7 @@ struct TowerArgs {
     int fallback;            // PREC 0 launch behind a PREC 1 one: only workgroups holding a flagged sample run
     int S, nblocks, hc;
     // tail handling (see nn_forward): role 0 = main launch, 1 / 2 = tail launches with fewer samples per workgroup
-    int role, S_main, S_small, S_mid, S_big, cus;
+    int role, S_main, S_small, S_mid, S_big, S_huge, cus;
     unsigned long long *stamp_out; // diagnostic build only
 };
 
@@ -1131,6 +1131,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
         if (tail > 0 && a.S_small > 0 && tail <= a.cus * a.S_small) mode = 1;
         else if (tail > 0 && a.S_mid > 0 && tail <= a.cus * a.S_mid) mode = 2;
         else if (tail > 0 && a.S_big > 0 && tail <= a.cus * a.S_big) mode = 3;
+        else if (tail > 0 && a.S_huge > 0 && tail <= a.cus * a.S_huge) mode = 4; // (main = two cout tiles per wave: role 4 = one round of the one-cout-tile kernel)
         if (a.role == 0) {
             if (mode) limit = n_full;
         } else {
@@ -2137,22 +2138,17 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         nn->S_c2 = Sc;
         nn->NT_c2 = ((Sc * HW + 15) / 16 + 3) / 4;           // tiles per wave (4 groups)
         nn->conv_lds_c2 = lds_bytes(Sc);
-        // tail launches (one round of smaller, faster workgroups for the samples behind the last full round): 1, 2, 3
-        // tiles per wave; a variant is dropped when it holds no more samples than the next smaller one
-        int prev = 0;
-        for (int k = 0; k < 3; k++) {
-            int sk = (k + 1) < nn->NT_c2 ? std::min((k + 1) * 64 / HW, Sc - 1) : 0;
-            if (sk <= prev) sk = 0; else prev = sk;
-            nn->S_c2_tail[k] = sk;
-        }
+        // worth it only where its 4 x NT_c2 tiles are filled about as well as the one-cout-tile kernel's NT (9x9: 200 of 256
+        // rows against 200 of 208)
+        const double fill_c2 = (double)Sc * HW / (64.0 * nn->NT_c2), fill_1 = (double)nn->S * HW / (16.0 * nn->NT);
+        if (fill_c2 < 0.97 * fill_1) nn->c2 = 0;
         if (nn->NT_c2 < 1 || nn->NT_c2 > 4) nn->c2 = 0;
     } else {
         nn->c2 = 0;
     }
     hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true);
     if (he == hipSuccess && nn->c2) he = tower_dispatch_c2(nn, nullptr, TowerArgs(), nn->NT_c2, 0, true);
-    for (int k = 0; k < 3; k++)
-        if (he == hipSuccess && nn->c2 && nn->S_c2_tail[k]) he = tower_dispatch_c2(nn, nullptr, TowerArgs(), k + 1, 0, true);
+
     if (he == hipSuccess && nn->mf32) he = tower_dispatch_mf(nn, nullptr, TowerArgs(), 2, 0, true);
     if (he == hipSuccess && nn->mf32) he = tower_dispatch_mf(nn, nullptr, TowerArgs(), 1, 0, true);
     if (he == hipSuccess && nn->tw32) he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true, 0);
@@ -2201,27 +2197,27 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     ta.overflow = nn->overflow; ta.ovf_flags = nn->ovf_flags; ta.fallback = 0; ta.S = nn->S; ta.nblocks = nn->blocks; ta.hc = hc;
     ta.stamp_out = nn->stamp_out;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.S_big = nn->S_big; ta.cus = nn->cus;
+    ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.S_big = nn->S_big; ta.S_huge = 0; ta.cus = nn->cus;
     ta.role = 0; ta.S = nn->S;
     if (nn->c2) {
-        // two cout tiles per wave (default for 64 channels): main launch + up to three tail launches, as below
-        ta.S_main = ta.S = nn->S_c2; ta.S_small = nn->S_c2_tail[0]; ta.S_mid = nn->S_c2_tail[1]; ta.S_big = nn->S_c2_tail[2];
+        // two cout tiles per wave (default for 64 channels) for the FULL rounds; what is left behind the last full round goes
+        // to one round of the one-cout-tile kernels, whose workgroups come in finer sizes (1, 2, 3 samples, or all S of them
+        // as role 4) -- or stays with this launch if it is more than such a round holds
+        ta.S_main = ta.S = nn->S_c2; ta.S_huge = nn->S;
         (void)tower_dispatch_c2(nn, s, ta, nn->NT_c2, (max_n + nn->S_c2 - 1) / nn->S_c2, false);
-        for (int k = 0; k < 3; k++)
-            if (nn->S_c2_tail[k] > 0) {
-                ta.role = k + 1; ta.S = nn->S_c2_tail[k];
-                (void)tower_dispatch_c2(nn, s, ta, k + 1, nn->cus, false);
-            }
-    } else if (nn->mf32) {
+        ta.role = 4; ta.S = nn->S;
+        (void)tower_dispatch(nn, s, ta, nn->NTT, nn->cus, false);
+    }
+    if (nn->mf32 && !nn->c2) {
         // 32x32x16 tiling: main launch + one tail launch of half-size workgroups (same split rule, derived from n on the device)
-        ta.S_main = ta.S = nn->S_mf; ta.S_small = nn->S_mf_tail; ta.S_mid = ta.S_big = 0;
+        ta.S_main = ta.S = nn->S_mf; ta.S_small = nn->S_mf_tail; ta.S_mid = ta.S_big = ta.S_huge = 0;
         (void)tower_dispatch_mf(nn, s, ta, nn->NT2, (max_n + nn->S_mf - 1) / nn->S_mf, false);
         if (nn->S_mf_tail > 0) {
             ta.role = 1; ta.S = nn->S_mf_tail;
             (void)tower_dispatch_mf(nn, s, ta, 1, nn->cus, false);
         }
     } else {
-    (void)tower_dispatch(nn, s, ta, nn->NTT, (max_n + nn->S - 1) / nn->S, false);
+    if (!nn->c2) (void)tower_dispatch(nn, s, ta, nn->NTT, (max_n + nn->S - 1) / nn->S, false);
     if (nn->S_small > 0) { // tail <= cus * S_small samples: one round of <2,2> workgroups
         ta.role = 1; ta.S = nn->S_small;
         (void)tower_dispatch(nn, s, ta, 2, nn->cus, false);
@@ -2239,7 +2235,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     if (nn->precision == 1 && nn->tw32 && !no_fb) {
         // safety net of the f16x3 mode: samples whose workgroup saw an activation leave f16's range are redone by the
         // exact-f32 tower (its workgroups check the per-sample flags on the device and leave at once otherwise)
-        ta.role = 0; ta.S = ta.S_main = nn->S; ta.S_small = ta.S_mid = ta.S_big = 0; ta.fallback = 1;
+        ta.role = 0; ta.S = ta.S_main = nn->S; ta.S_small = ta.S_mid = ta.S_big = ta.S_huge = 0; ta.fallback = 1;
         ta.tw = nn->tw32; ta.tb = nn->tb32; ta.w0p = nullptr; ta.hwp = nullptr;
         (void)tower_dispatch(nn, s, ta, nn->NTT, std::min((max_n + nn->S - 1) / nn->S, nn->cus), false, 0);
     }
