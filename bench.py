@@ -511,18 +511,21 @@ def main():
                                     "frac": exp * bps / t_tree / 1e9 / 8000.0, "bytes_per_sim": bps,
                                     "note": "latency-bound pointer chase (one wave per game, ~L dependent node "
                                             "visits per sim); a low HBM fraction is expected (SURVEY 8d)"}
-            pmc = os.path.join(REPO, "profiles", "r01_pmc_tower.json")
-            if os.path.exists(pmc) and args.precision == 1 and (args.board, args.slots) == (6, 8192):
+            pmc = os.path.join(REPO, "profiles", "r02_pmc_tower_16x16x32_two_cout_tiles_3840evals.json")
+            if os.path.exists(pmc) and args.precision == 1 and (args.board, args.channels, args.blocks) == (6, 64, 20):
+                # PMC passes cannot run inside this process: the counters of the same kernel, collected by tools/pmc_bench.sh on
+                # launches of exactly 3 rounds (3 838 evaluations), scaled to the rounds of THIS run's launches
                 t = json.load(open(pmc))
-                out["roofline"]["traffic"] = t.get("traffic_bytes_per_launch")
-                out["roofline"]["traffic_note"] = t.get("note")
+                evals = m["nn_evals"] / args.steps
+                rounds = evals / (256.0 * 5)
+                out["roofline"]["traffic"] = t.get("traffic_bytes_per_launch") / 3.0 * rounds
+                out["roofline"]["traffic_note"] = (
+                    "(2*FETCH_SIZE + WRITE_SIZE)*1024 B of the main k_tower launch, measured on 3-round launches "
+                    "(profiles/r02_pmc_tower_16x16x32_two_cout_tiles_3840evals.json: 186.6 MB) and scaled to this run's %.2f rounds; "
+                    "per round the 5.9 MB of packed weights are re-streamed Infinity-Cache -> L2 by each of the 8 XCDs (they exceed "
+                    "the 4 MiB L2), not from HBM; algorithmic bytes per launch = features in + head activations out + weights "
+                    "once = %.1f MB" % (rounds, (evals * (588 + 6272) + 5.9e6) / 1e6))
                 out["roofline"]["mfma_busy_frac"] = t.get("mfma_busy_frac")
-                ks = t.get("kernels", {})
-                if "k_select" in ks and "k_expand_backup" in ks:  # same PMC passes, tree kernels
-                    out["roofline_tree"]["traffic"] = sum(
-                        (2.0 * ks[k]["FETCH_SIZE"]["mean"] + ks[k]["WRITE_SIZE"]["mean"]) * 1024.0
-                        for k in ("k_select", "k_expand_backup"))
-                    out["roofline_tree"]["algorithmic_bytes_per_step"] = bps * exp / args.steps
             else:
                 out["roofline"]["traffic"] = None
         else:
