@@ -98,7 +98,7 @@ def load():
     L.dbaz_set_positions.argtypes = [vp, vp, vp]
     L.dbaz_search.argtypes = [vp, vp, vp]
     L.dbaz_search_timed.argtypes = [vp, vp, vp, C.c_double]
-    L.dbaz_set_pending.argtypes = [vp, i32]
+    L.dbaz_set_pending.argtypes = [vp, i32, i32]
     L.dbaz_search_begin.argtypes = [vp, vp, vp]
     L.dbaz_select.argtypes = [vp, vp, vp, vp]
     L.dbaz_expand_backup.argtypes = [vp, vp, vp]

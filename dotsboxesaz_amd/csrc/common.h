@@ -123,6 +123,7 @@ struct SearchCfg {
     int driver_concurrent;   // this k_select runs next to the driver pass of the same step (self-play stepping)
     int quick_reads;         // read budget of the quick plies (dbaz_selfplay_quickplay)
     int pending;             // K > 1 search: width of a wave (<= TreeBufs.kmax), dbaz_set_pending
+    int virtual_visits;      // K > 1 search: 1 = a simulation's visit is counted on its path at selection, 0 = at backup (the reference)
 };
 
 // device buffer bundle handed to the tree kernels

@@ -226,6 +226,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     sc.evaluator = cfg->evaluator; sc.seed = cfg->seed;
     sc.match_play = cfg->match_play ? 1 : 0; sc.evaluator2 = cfg->evaluator2;
     sc.pending = cfg->max_pending_evals > 1 ? cfg->max_pending_evals : 1;
+    sc.virtual_visits = 1;
 
     TreeBufs &B = e->B;
     memset(&B, 0, sizeof(B));
@@ -683,12 +684,13 @@ extern "C" int dbaz_search_begin(dbaz_engine *e, const int32_t *num_reads, const
     return DBAZ_OK;
 }
 
-extern "C" int dbaz_set_pending(dbaz_engine *e, int32_t k)
+extern "C" int dbaz_set_pending(dbaz_engine *e, int32_t k, int32_t virtual_visits)
 {
     if (!e) return DBAZ_EINVAL;
     if (e->B.kmax <= 1) return set_error(e, DBAZ_ESTATE, "the handle was created with max_pending_evals <= 1");
     if (k < 1 || k > e->B.kmax) return set_error(e, DBAZ_EINVAL, "pending evaluations must be in 1..%d", e->B.kmax);
     e->sc.pending = k;
+    e->sc.virtual_visits = virtual_visits ? 1 : 0;
     return DBAZ_OK;
 }
 

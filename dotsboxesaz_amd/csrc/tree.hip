@@ -878,8 +878,9 @@ __device__ __forceinline__ void select_multi_one(const Geo &g, const SearchCfg &
 #pragma unroll
         for (int j = 0; j < NPL; j++) rp[j] = (lane + WAVE * j < A) ? rprior[lane + WAVE * j] : 0.0;
         in_move = m.move;
+        const unsigned vv = cfg.virtual_visits ? 1u : 0u;
         if (lane == 0) {
-            S->root_N = Nself + 1;                              // the visit is counted now (backup adds the value only)
+            S->root_N = Nself + (int)vv;                        // virtual_visits: the visit is counted now (backup adds the value only)
             if ((m.flags & NF_EXPANDED) && !(m.flags & NF_TERMINAL)) S->root_W = S->root_W - 1.0f;
         }
         while ((m.flags & NF_EXPANDED) && !(m.flags & NF_TERMINAL)) {
@@ -952,7 +953,7 @@ __device__ __forceinline__ void select_multi_one(const Geo &g, const SearchCfg &
                 bool same = (st.to_play == st.just_played);
                 if (lane == 0) {
                     Crow[bi] = child;
-                    NSrow[bi] = (same ? NS_SAME : 0u) | 1u;   // child_player_changed slot; the pending visit
+                    NSrow[bi] = (same ? NS_SAME : 0u) | vv;   // child_player_changed slot; the pending visit
                 }
                 init_node(pool, g, child, st, cur, bi, m.deepness + 1, lane);
                 NodeMeta cm;
@@ -970,7 +971,7 @@ __device__ __forceinline__ void select_multi_one(const Geo &g, const SearchCfg &
             load_rows<NPL>(R, pool, g, child, lane);
             select_tab_fix(cfg, nchild, pbc_nx, sq_nx);
             if (lane == owner) {
-                NSrow[bi] = bns + 1u;                           // the visit of the edge into `child`, counted now
+                if (vv) NSrow[bi] = bns + 1u;                   // the visit of the edge into `child`, counted now
                 if ((cm.flags & NF_EXPANDED) && !(cm.flags & NF_TERMINAL)) Wrow[bi] = bw - 1.0f; // VIRTUAL_LOSS on the node left next
             }
             if ((cm.flags & NF_EXPANDED) && !(cm.flags & NF_TERMINAL)) {
@@ -1008,7 +1009,7 @@ __device__ __forceinline__ void select_multi_one(const Geo &g, const SearchCfg &
         if (err) { S->error = err; S->phase = PH_ERROR; }
         S->wave_sims = done;
         S->sel_step = cfg.step;
-        S->first_wave = 0;
+        if (phase == PH_SIMS) S->first_wave = 0; // (the root expansion is not one of the waves)
         pool_store(q, S);
         if (q.n_nodes > S->pool_high) S->pool_high = q.n_nodes;
     }
@@ -1085,7 +1086,7 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup_multi(Geo g, SearchCfg c
             if (lane == 0) nd[12] = __float_as_uint(v);
         }
         if (lane == 0) nd[11] = pack_dw11((lm.flags | NF_EXPANDED) & ~NF_INFLIGHT, lm.result, lm.deepness);
-        // backup: W += v_n + VIRTUAL_LOSS on every path node; the visits were counted at selection
+        // backup: W += v_n + VIRTUAL_LOSS on every path node; N += 1 here (the reference) or already at selection (virtual_visits)
         const int tp = lm.st.to_play;
         for (int d = lane; d < sr.path_len; d += WAVE) {
             PathEnt pe = path[d];
@@ -1093,10 +1094,12 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup_multi(Geo g, SearchCfg c
             float add = vn + 1.0f;
             if (d == 0) {
                 S->root_W = S->root_W + add;
+                if (!cfg.virtual_visits) S->root_N = S->root_N + 1;
             } else {
                 uint32_t *pn = node_ptr(pool, g, path[d - 1].node);
                 float *Wr = reinterpret_cast<float *>(pn + META_DW + g.AS);
                 Wr[pe.move_in] = Wr[pe.move_in] + add;
+                if (!cfg.virtual_visits) pn[META_DW + 2 * g.AS + pe.move_in] += 1u;
             }
         }
         if (lane == 0) {

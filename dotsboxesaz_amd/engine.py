@@ -187,9 +187,10 @@ class Engine:
         nr, nz = self._search_args(num_reads, noise)
         self._ck(self._L.dbaz_search(self.h, _p(nr), _p(nz)))
 
-    def set_pending(self, k):
-        """max_pending_evals of the following searches (1..the handle's max_pending_evals)."""
-        self._ck(self._L.dbaz_set_pending(self.h, int(k)))
+    def set_pending(self, k, virtual_visits=True):
+        """max_pending_evals of the following searches (1..the handle's max_pending_evals).  virtual_visits=False: the
+        reference's bookkeeping (visits added at backup); True: also counted on the path at selection time."""
+        self._ck(self._L.dbaz_set_pending(self.h, int(k), int(bool(virtual_visits))))
 
     def search_timed(self, time_limit, num_reads=None, noise=None):
         """UCT_search with its wall-clock cut-off (seconds; None / 0 = the reference's 120 s default)."""

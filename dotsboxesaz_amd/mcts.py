@@ -118,8 +118,9 @@ def create_root_uct_node(game_state, nodes_per_slot=0, mcts_num_read=800, nn=Non
 
 
 async def UCT_search(root_node, num_reads, async_nn, cpuct=(1.25, 19652), max_pending_evals=64, dirichlet=(0.0, 0.0),
-                     time_limit=None):
-    """mcts.py:183-244 -> np.int32[A] root child visit counts."""
+                     time_limit=None, virtual_visits=True):
+    """mcts.py:183-244 -> np.int32[A] root child visit counts.  virtual_visits (device evaluator only): False = the
+    reference's bookkeeping of pending simulations, True = their visits also count at selection time."""
     e = root_node._e
     alpha, coeff = dirichlet
     e.set_search_params(cpuct, dirichlet)
@@ -134,7 +135,7 @@ async def UCT_search(root_node, num_reads, async_nn, cpuct=(1.25, 19652), max_pe
         # launch per wave, the clock read between waves (dbaz_search_timed); `async_nn` is not called
         kmax = int(e.cfg.max_pending_evals)
         if kmax > 1:
-            e.set_pending(max(1, min(int(max_pending_evals), kmax)))
+            e.set_pending(max(1, min(int(max_pending_evals), kmax)), virtual_visits)
         e.search_timed(time_limit, reads, noise)
         root_node._refresh()
         return root_node.child_number_visits

@@ -160,8 +160,13 @@ int dbaz_search(dbaz_engine *e, const int32_t *num_reads, const double *noise);
  * elapsed are dropped; the root expansion is never cut; the clock is read between waves */
 int dbaz_search_timed(dbaz_engine *e, const int32_t *num_reads, const double *noise, double time_limit_s);
 /* per-call max_pending_evals of a handle created with max_pending_evals = K > 1: 1 <= k <= K simulations in flight
- * (k = 1 through the same kernels reproduces the sequential search bit for bit) */
-int dbaz_set_pending(dbaz_engine *e, int32_t k);
+ * (k = 1 through the same kernels reproduces the sequential search bit for bit).
+ * virtual_visits = 0: the reference's bookkeeping -- a simulation's visits are added at backup, only `total_value -=
+ * VIRTUAL_LOSS` marks its path while it is pending (mcts.py:105-132); with an evaluator that suspends once per call
+ * the reference's searches run in exactly these waves, and the results are equal bit for bit (tests/golden/pending.npz).
+ * virtual_visits = 1 (default): the visit is counted on every edge of the path at selection time as well, so the
+ * simulations of a wave spread over the tree (the reference's in-flight leaves are mostly duplicates). */
+int dbaz_set_pending(dbaz_engine *e, int32_t k, int32_t virtual_visits);
 /* external-evaluator form of the same call: begin, then loop
  *   dbaz_select -> (evaluate leaves on the host) -> dbaz_expand_backup  until *n_active == 0 */
 int dbaz_search_begin(dbaz_engine *e, const int32_t *num_reads, const double *noise);

@@ -12,6 +12,8 @@ Outputs are data only (inputs + the reference's outputs):
                    with the resulting states
     mcts.npz       sequential UCT_search (max_pending_evals=1) root arrays/stats
                    under a formula-defined evaluator                           (M1-M9)
+    pending.npz    UCT_search with max_pending_evals = K > 1 and an evaluator that
+                   suspends once per call (synchronous waves)                   (8f-4)
     nn.npz         ResNetZero / SimpleNN outputs on committed / seeded weights  (N1-N3)
     selfplay.npz   SelfPlay.play_game + get_datasets with recorded RNG draws    (D1-D3)
     match.npz      two-model match play rows (self_play.compute_elo's loop)     (8f-3)
@@ -296,6 +298,85 @@ def gen_mcts():
 
 
 # ---------------------------------------------------------------- nn
+def gen_pending():
+    """UCT_search with max_pending_evals = K > 1 (mcts.py:228-239) under an evaluator that suspends exactly once
+    (`await asyncio.sleep(0)`): the K searches of a wave then select one after the other, and expand + back up one after
+    the other when the event loop comes round again -- the schedule the build's k_select_multi / k_expand_backup_multi
+    implement (with virtual_visits = 0)."""
+    out = {}
+    cases = []
+
+    def make_nn(kind):
+        async def nn(state):
+            await asyncio.sleep(0)
+            return formula_eval(state, kind)
+        return nn
+
+    def add_case(name, rows, cols, start_moves, kind, K, script, cpuct=(1.25, 19652)):
+        set_board(rows, cols)
+        s = BoxesState()
+        for m in start_moves:
+            s.play_(m)
+        node = ref_mcts.create_root_uct_node(s)
+        nn = make_nn(kind)
+        import zlib
+        rng = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
+        A = s.get_actions_size()
+        steps = []
+        si = 0
+        for op in script:
+            if op[0] == "search":
+                _, n, alpha, coeff = op
+                noise = None
+                if alpha > 0:
+                    noise = rng.dirichlet(np.full(A, alpha))
+                    orig = np.random.dirichlet
+                    np.random.dirichlet = lambda a, size=None, _n=noise: _n.reshape(1, -1).copy()
+                try:
+                    vc = run(ref_mcts.UCT_search(node, n, nn, cpuct, K, (alpha, coeff)))
+                finally:
+                    if alpha > 0:
+                        np.random.dirichlet = orig
+                rec = root_record(node)
+                assert np.array_equal(vc, rec["visits"])
+                k = "%s_s%d_" % (name, si)
+                for f, v in rec.items():
+                    out[k + f] = np.asarray(v)
+                out[k + "noise"] = noise if noise is not None else np.zeros(0)
+                steps.append((0, n, alpha, coeff))
+            else:
+                _, mv, reuse = op
+                if mv < 0:
+                    mv = int(np.argmax(node.child_number_visits))
+                node = ref_mcts.init_mcts_tree(node, mv, reuse_tree=bool(reuse))
+                steps.append((1, mv, float(reuse), 0.0))
+            si += 1
+        out[name + "_script"] = np.array(steps, dtype=np.float64)
+        out[name + "_cfg"] = np.array([rows, cols, kind, cpuct[0], cpuct[1], K], dtype=np.float64)
+        out[name + "_start"] = np.array(start_moves, dtype=np.int16)
+        cases.append(name)
+
+    S = lambda n, a=0.0, c=0.0: ("search", n, a, c)  # noqa: E731
+    ADV = lambda mv=-1, reuse=1: ("advance", mv, reuse)  # noqa: E731
+    csv = {r[0]: r for r in load_csv()}
+    for K in (2, 4, 8, 64):
+        add_case("p33_K%d_n100" % K, 3, 3, [], 0, K, [S(100)])
+    add_case("p33_K8_n7", 3, 3, [], 0, 8, [S(7)])               # fewer reads than one wave
+    add_case("p33_K64_n65", 3, 3, [], 0, 64, [S(65)])             # first wave min(K, A) = 32, then 33
+    add_case("p33_K5_uniform", 3, 3, [], 1, 5, [S(120)])
+    add_case("p33_K16_csv5", 3, 3, csv[5][1], 0, 16, [S(150)])
+    add_case("p33_K8_end", 3, 3, csv[4][1], 0, 8, [S(60), ADV(), S(60), ADV(), S(24)])   # terminal leaves in the waves
+    add_case("p33_K8_seq", 3, 3, [], 0, 8, [S(100), ADV(), S(100), ADV(), S(60, 0.8, 0.25), ADV(), S(100)])
+    add_case("p33_K8_fresh", 3, 3, [], 0, 8, [S(80), ADV(-1, 0), S(80)])
+    add_case("p66_K8_n200", 6, 6, [], 0, 8, [S(200)])
+    add_case("p66_K64_seq", 6, 6, [], 0, 64, [S(300), ADV(), S(300, 0.8, 0.25), ADV(), S(200)])
+    add_case("p99_K64_n400", 9, 9, [], 0, 64, [S(400)])
+    add_case("p23_K16_n150", 2, 3, [], 0, 16, [S(150)])
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "pending.npz"), **out)
+    print("pending.npz", len(cases), "cases")
+
+
 def ref_resnet_params(rows, cols, channels, blocks, head_ch, value_fc):
     from utils.utils import DotDict
     H, W = rows + 1, cols + 1
@@ -700,7 +781,7 @@ def gen_train():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="rules,boards,mcts,nn,selfplay,match,train")
+    ap.add_argument("--only", default="rules,boards,mcts,pending,nn,selfplay,match,train")
     args = ap.parse_args()
     todo = args.only.split(",")
     if "rules" in todo:
@@ -709,6 +790,8 @@ if __name__ == "__main__":
         gen_boards_csv()
     if "mcts" in todo:
         gen_mcts()
+    if "pending" in todo:
+        gen_pending()
     if "nn" in todo:
         gen_nn()
     if "selfplay" in todo:

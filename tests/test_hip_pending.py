@@ -1,8 +1,12 @@
 """UCT_search with several pending evaluations on one tree (mcts.py:228-239; players.AZPlayer):
-k_select_multi / k_expand_backup_multi through the C ABI.  With one simulation in flight the kernels must reproduce the
-sequential search -- the reference's golden scripts and the oracle -- bit for bit; with K > 1 (our synchronous-wave
-semantics with counted virtual visits: parity unpinned, the reference's asyncio interleaving is not reproduced) the
-bookkeeping identities of mcts.py hold, results are deterministic, and the wall-clock cut-off works."""
+k_select_multi / k_expand_backup_multi through the C ABI.
+  * one simulation in flight: the kernels reproduce the sequential search -- the 35 golden scripts -- bit for bit;
+  * K > 1 with the reference's bookkeeping (virtual_visits = 0): bit-exact against tests/golden/pending.npz, i.e. against the
+    reference's own UCT_search(..., max_pending_evals=K) under an evaluator that suspends once per call (its asyncio loop
+    then runs the searches in synchronous waves of K; other evaluator schedules -- the batching proxy's 50 ms timer --
+    interleave differently and are not reproduced);
+  * K > 1 with counted virtual visits (the default of the AZPlayer mirror; not a reference mode: parity unpinned): the
+    bookkeeping identities of mcts.py, determinism, and the wall-clock cut-off."""
 import time
 
 import numpy as np
@@ -151,3 +155,45 @@ def test_az_player_mirror_time_limited_move():
     assert move is not None and s.get_valid_moves()[move] and policy[move] == policy.max() > 0
     assert policy.sum() > 500 and 0.25 < dt < 5.0 and rate > 1000
     assert (policy[~np.asarray(s.get_valid_moves(), bool)] == 0).all()
+
+
+# ---- K > 1 against the reference itself: tests/golden/pending.npz holds UCT_search(..., max_pending_evals=K) of the
+# reference under an evaluator that suspends once per call, which makes its asyncio loop run the searches in synchronous
+# waves of K (first wave min(K, A)): K selections, then K expand + backups.  With virtual_visits = 0 the device kernels keep
+# the reference's bookkeeping and must agree bit for bit -- duplicates of a pending leaf, terminal leaves, partial last waves,
+# tree reuse and noise included.
+_P = load_golden("pending.npz")
+PCASES = [str(c) for c in _P["cases"]]
+
+
+@pytest.mark.parametrize("name", PCASES)
+def test_pending_waves_equal_reference_golden(name):
+    from dotsboxesaz_amd.engine import Engine
+    g = _P
+    rows, cols, kind, c0, c1, K = g[name + "_cfg"]
+    K = int(K)
+    e = Engine(int(rows), int(cols), 2, mcts_num_read=800, evaluator="uniform" if kind == 1 else "formula", max_pending_evals=K)
+    e.set_pending(K, virtual_visits=False)
+    st = list(g[name + "_start"])
+    e.set_positions([st, st])
+    shared = 0
+    for si, (op, a, b, c) in enumerate(g[name + "_script"]):
+        key = "%s_s%d_" % (name, si)
+        if op == 0:
+            e.set_search_params((c0, c1), (b, c))
+            e.search(int(a), None if b <= 0 else np.stack([g[key + "noise"]] * 2))
+            r = e.roots()
+            for s in (0, 1):
+                assert np.array_equal(r["visits"][s], g[key + "visits"]), key
+                assert np.array_equal(r["total_value"][s].view(np.uint32), g[key + "total_value"].view(np.uint32)), key
+                assert np.array_equal(r["priors"][s].view(np.uint64), g[key + "priors"].view(np.uint64)), key
+                assert np.array_equal(r["changed"][s], g[key + "changed"]), key
+                assert list(r["stats"][s]) == list(g[key + "stats_i"]), key
+                assert r["q"][s].view(np.uint32) == g[key + "q"].view(np.uint32), key
+                assert r["root_nv"][s] == g[key + "root_nv"] and r["root_tv"][s].view(np.uint32) == g[key + "root_tv"].view(np.uint32)
+        else:
+            e.advance(int(a), bool(b))
+    shared = e.counters()["cache_hits"]
+    if K >= 8 and "n7" not in name:
+        assert shared > 0  # the reference's pending simulations do pile onto the same leaves; they share one evaluation here
+    e.close()
