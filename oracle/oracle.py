@@ -99,6 +99,9 @@ def lib():
         L.ob_uct_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(SearchParams),
                                     C.c_void_p, C.c_void_p]
         L.ob_uct_search.restype = C.c_int
+        L.ob_uct_search_pending.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(SearchParams),
+                                            C.c_void_p, C.c_void_p]
+        L.ob_uct_search_pending.restype = C.c_int
         L.ob_tree_advance.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ob_tree_advance.restype = C.c_void_p
         L.ob_tree_state.argtypes = [C.c_void_p]
@@ -229,15 +232,16 @@ class Tree:
             lib().ob_tree_free(self.ptr)
             self.ptr = None
 
-    def search(self, num_reads, evaluator, cpuct=(1.25, 19652), dirichlet=(0.0, 0.0), noise=None):
+    def search(self, num_reads, evaluator, cpuct=(1.25, 19652), dirichlet=(0.0, 0.0), noise=None, max_pending=1):
+        """UCT_search; max_pending > 1: mcts.py:228-239 under an evaluator that suspends once per call (waves)."""
         sp = search_params(cpuct, dirichlet)
         vis = np.zeros(self.d.A, dtype=np.int32)
         nz = None
         if dirichlet[0] > 0:
             nz = np.ascontiguousarray(noise, dtype=np.float64)
             assert nz.size == self.d.A
-        lib().ob_uct_search(self.ptr, int(num_reads), evaluator.fn_ptr, evaluator.user, C.byref(sp),
-                            nz.ctypes.data if nz is not None else None, vis.ctypes.data)
+        lib().ob_uct_search_pending(self.ptr, int(num_reads), int(max_pending), evaluator.fn_ptr, evaluator.user, C.byref(sp),
+                                    nz.ctypes.data if nz is not None else None, vis.ctypes.data)
         return vis
 
     def advance(self, move, reuse_tree=True):

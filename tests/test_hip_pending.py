@@ -197,3 +197,45 @@ def test_pending_waves_equal_reference_golden(name):
     if K >= 8 and "n7" not in name:
         assert shared > 0  # the reference's pending simulations do pile onto the same leaves; they share one evaluation here
     e.close()
+
+
+@pytest.mark.parametrize("rows,cols,n_slots,sims,K", [(3, 3, 96, 150, 8), (6, 6, 48, 300, 64), (4, 2, 40, 90, 3), (9, 9, 12, 250, 64),
+                                                       (6, 6, 32, 200, 16)])
+def test_pending_waves_many_slots_vs_oracle(rows, cols, n_slots, sims, K):
+    """Every slot searches a different position with its own read count; three searches with tree reuse, noise on the second:
+    root arrays against the oracle's wave search (itself pinned to the reference by pending.npz), slot by slot."""
+    from dotsboxesaz_amd.engine import Engine
+    d = O.dims(rows, cols)
+    rng = np.random.RandomState(K * 1000 + sims)
+    starts = _starts(d, n_slots, rng)
+    e = Engine(rows, cols, n_slots, mcts_num_read=sims, evaluator="formula", max_pending_evals=K)
+    e.set_pending(K, virtual_visits=False)
+    e.set_positions(starts)
+    trees = [O.Tree(d, O.state_from_moves(d, mv)) for mv in starts]
+    ev = O.Evaluator(0)
+    reads = rng.randint(1, sims + 1, size=n_slots).astype(np.int32)
+    for rnd, (alpha, coeff) in enumerate([(0.0, 0.0), (0.8, 0.25), (0.0, 0.0)]):
+        noise = rng.dirichlet(np.full(d.A, 0.8), size=n_slots) if alpha > 0 else None
+        e.set_search_params((1.25, 19652), (alpha, coeff))
+        e.search(reads, noise)
+        r = e.roots()
+        moves = np.zeros(n_slots, np.int32)
+        for s in range(n_slots):
+            vis = trees[s].search(int(reads[s]), ev, dirichlet=(alpha, coeff), noise=None if noise is None else noise[s],
+                                  max_pending=K)
+            pri, tv, nv, pc = trees[s].root_arrays()
+            assert np.array_equal(r["visits"][s], vis), (rnd, s)
+            assert np.array_equal(r["total_value"][s].view(np.uint32), tv.view(np.uint32)), (rnd, s)
+            assert np.array_equal(r["priors"][s].view(np.uint64), pri.view(np.uint64)), (rnd, s)
+            md, ts, tc, q = trees[s].stats()
+            assert list(r["stats"][s]) == [md, ts, tc] and r["q"][s].view(np.uint32) == np.float32(q).view(np.uint32)
+            moves[s] = int(np.argmax(vis)) if s % 2 == 0 else int(rng.choice(np.nonzero(O.valid_moves(d, trees[s].state))[0]))
+        for s in range(n_slots):
+            tmp = trees[s].state
+            O.play_(d, tmp, int(moves[s]))
+            if O.get_result(tmp) is not None:
+                moves[s] = -1
+            else:
+                trees[s].advance(int(moves[s]), True)
+        e.advance(moves, True)
+    e.close()

@@ -80,3 +80,35 @@ def test_illegal_advance_raises():
     t.advance(0)
     with pytest.raises(ValueError):
         t.advance(0)
+
+
+# ---- max_pending_evals = K > 1: the oracle's wave search vs the reference's UCT_search under a
+# once-suspending evaluator (tests/golden/pending.npz, written by gen_golden.py --only pending)
+_P = load_golden("pending.npz")
+PCASES = [str(c) for c in _P["cases"]]
+
+
+@pytest.mark.parametrize("name", PCASES)
+def test_oracle_pending_waves_match_reference(name):
+    g = _P
+    rows, cols, kind, c0, c1, K = g[name + "_cfg"]
+    d = O.dims(int(rows), int(cols))
+    t = O.Tree(d, O.state_from_moves(d, g[name + "_start"]))
+    ev = O.Evaluator(int(kind))
+    for si, (op, a, b, c) in enumerate(g[name + "_script"]):
+        key = "%s_s%d_" % (name, si)
+        if op == 0:
+            vis = t.search(int(a), ev, cpuct=(c0, c1), dirichlet=(b, c), noise=g[key + "noise"] if b > 0 else None,
+                           max_pending=int(K))
+            pri, tv, nv, pc = t.root_arrays()
+            assert np.array_equal(vis, g[key + "visits"]), key
+            assert np.array_equal(tv.view(np.uint32), g[key + "total_value"].view(np.uint32)), key
+            assert np.array_equal(pri.view(np.uint64), g[key + "priors"].view(np.uint64)), key
+            assert np.array_equal(pc, g[key + "changed"]), key
+            md, ts, tc, q = t.stats()
+            assert [md, ts, tc] == list(g[key + "stats_i"]), key
+            assert np.float32(q).view(np.uint32) == g[key + "q"].view(np.uint32), key
+            rtv, rnv = t.root_slot()
+            assert rnv == g[key + "root_nv"] and np.float32(rtv).view(np.uint32) == g[key + "root_tv"].view(np.uint32)
+        else:
+            t.advance(int(a), bool(b))
