@@ -1136,10 +1136,12 @@ extern "C" int dbaz_fetch_samples(dbaz_engine *e, int32_t max_rows, int32_t *n_r
     std::vector<RowMeta> meta(n);
     std::vector<int16_t> hx((size_t)n * F);
     std::vector<int32_t> hv((size_t)n * A);
-    HIP_CHECK_RET(e, hipMemcpy(meta.data(), e->B.out_meta, sizeof(RowMeta) * n, hipMemcpyDeviceToHost));
-    HIP_CHECK_RET(e, hipMemcpy(hx.data(), e->B.out_x, (size_t)n * F * 2, hipMemcpyDeviceToHost));
-    HIP_CHECK_RET(e, hipMemcpy(hv.data(), e->B.out_vis, (size_t)n * A * 4, hipMemcpyDeviceToHost));
-    HIP_CHECK_RET(e, hipMemset(e->B.out_count, 0, 4));
+    // one trip: the three row arrays and the counter reset are queued on the stream, then ONE synchronisation
+    HIP_CHECK_RET(e, hipMemcpyAsync(meta.data(), e->B.out_meta, sizeof(RowMeta) * n, hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK_RET(e, hipMemcpyAsync(hx.data(), e->B.out_x, (size_t)n * F * 2, hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK_RET(e, hipMemcpyAsync(hv.data(), e->B.out_vis, (size_t)n * A * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK_RET(e, hipMemsetAsync(e->B.out_count, 0, 4, e->stream));
+    HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
     std::vector<int> order(n);
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int a, int b) {
