@@ -1526,7 +1526,7 @@ NNState *nn_create(const Geo &g, int max_batch, int precision)
     nn->g = g;
     nn->max_batch = max_batch;
     nn->precision = precision == 2 ? 1 : precision; // 2 = the f16x3 arithmetic of 1 on the 32x32x16 MFMA tiling
-    nn->want_mf32 = precision == 2 || getenv("DBAZ_MF32") != nullptr;
+    nn->want_mf32 = precision == 2;
     // 1 = f16x3 on the default tiling (two cout tiles per wave for 64-channel networks, one otherwise), 3 = the former and
     // 4 = the latter explicitly (A/B measurements; the three give bit-identical results)
     nn->want_c2 = precision == 1 || precision == 3;
