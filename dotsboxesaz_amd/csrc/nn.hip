@@ -85,7 +85,8 @@ struct NNState {
     int want_mf32 = 0, mf32 = 0, S_mf = 0, NT2 = 0, S_mf_tail = 0;
     size_t conv_lds_mf = 0;
     // f16x3 on 16x16x32 with two cout tiles per wave (k_tower<64, NT, 0, 1, 2>, 64 channels): 4 tile groups of NT_c2 tiles
-    int want_c2 = 0, c2 = 0, S_c2 = 0, NT_c2 = 0; // (its tail launches are the one-cout-tile kernels below)
+    int want_c2 = 0, c2 = 0, S_c2 = 0, NT_c2 = 0; // (its remainder goes to the one-cout-tile kernels)
+    int use_rem = 0; // f16x3, NTT == 7: the remainder sizes live in ONE launch (k_tower_rem)
     size_t conv_lds_c2 = 0;
 };
 
@@ -1112,6 +1113,21 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
 #endif
 }
 
+// which launch takes the samples behind the last full round of the main launch: 0 = the main launch itself, 1..4 = one
+// round of workgroups with S_small / S_mid / S_big / S_huge samples each (every launch derives this from n on the device)
+__device__ __forceinline__ int tower_split(const TowerArgs &a, int n, int &n_full)
+{
+    const int per_round = a.cus * a.S_main;
+    n_full = per_round > 0 ? (n / per_round) * per_round : 0;
+    const int tail = n - n_full;
+    if (tail <= 0) return 0;
+    if (a.S_small > 0 && tail <= a.cus * a.S_small) return 1;
+    if (a.S_mid > 0 && tail <= a.cus * a.S_mid) return 2;
+    if (a.S_big > 0 && tail <= a.cus * a.S_big) return 3;
+    if (a.S_huge > 0 && tail <= a.cus * a.S_huge) return 4; // (main = two cout tiles per wave: 4 = one round of the one-cout-tile kernel)
+    return 0;
+}
+
 template <int C, int NTA, int NTB, int PREC, int MF = 0>
 __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 {
@@ -1124,14 +1140,8 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     // those smaller, faster workgroups can take them; every launch derives the split from n on the device.
     int first_sample = 0, limit = n;
     {
-        const int per_round = a.cus * a.S_main;
-        const int n_full = per_round > 0 ? (n / per_round) * per_round : 0;
-        const int tail = n - n_full;
-        int mode = 0;
-        if (tail > 0 && a.S_small > 0 && tail <= a.cus * a.S_small) mode = 1;
-        else if (tail > 0 && a.S_mid > 0 && tail <= a.cus * a.S_mid) mode = 2;
-        else if (tail > 0 && a.S_big > 0 && tail <= a.cus * a.S_big) mode = 3;
-        else if (tail > 0 && a.S_huge > 0 && tail <= a.cus * a.S_huge) mode = 4; // (main = two cout tiles per wave: role 4 = one round of the one-cout-tile kernel)
+        int n_full;
+        const int mode = tower_split(a, n, n_full);
         if (a.role == 0) {
             if (mode) limit = n_full;
         } else {
@@ -1176,6 +1186,27 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     const int s0 = first_sample + blockIdx.x * S;
     if (s0 >= limit) return;
     tower_group<C, NTA, NTB, PREC, MF>(g, a, lds, S, s0, min(S, limit - s0));
+}
+
+// The remainder of a batch in ONE launch (f16x3, one-cout-tile tiling): the workgroups pick the size the split asks for --
+// <2,2> / <4,4> / <5,5> / <7,6> tiles per wave half, S_small / S_mid / S_big / S_huge samples -- instead of four launches of
+// which three leave at once (5 us each: 1 % of a 6x6 step, 4 % of a 3x3 step).
+template <int C>
+__global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_rem(Geo g, TowerArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n = *a.n_dev;
+    int n_full;
+    const int mode = tower_split(a, n, n_full);
+    if (mode == 0) return;
+    const int S = mode == 1 ? a.S_small : mode == 2 ? a.S_mid : mode == 3 ? a.S_big : a.S_huge;
+    const int s0 = n_full + blockIdx.x * S;
+    if (s0 >= n) return;
+    const int ns = min(S, n - s0);
+    if (mode == 1) tower_group<C, 2, 2, 1, 0>(g, a, lds, S, s0, ns);
+    else if (mode == 2) tower_group<C, 4, 4, 1, 0>(g, a, lds, S, s0, ns);
+    else if (mode == 3) tower_group<C, 5, 5, 1, 0>(g, a, lds, S, s0, ns);
+    else tower_group<C, 7, 6, 1, 0>(g, a, lds, S, s0, ns);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1718,6 +1749,21 @@ static hipError_t tower_inst_mf(NNState *nn, hipStream_t s, const TowerArgs &ta,
         return hipErrorInvalidValue;
     }
 }
+// the remainder launch (f16x3, geometries whose main one-cout-tile instantiation is <7,6>)
+static hipError_t tower_dispatch_rem(NNState *nn, hipStream_t s, const TowerArgs &ta, int grid, bool attr_only)
+{
+#define REM_CASE(CC)                                                                                                                  \
+    case CC:                                                                                                                          \
+        if (attr_only) return hipFuncSetAttribute((const void *)k_tower_rem<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds); \
+        hipLaunchKernelGGL((k_tower_rem<CC>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);                            \
+        return hipSuccess;
+    switch (nn->C) {
+        REM_CASE(32) REM_CASE(64) REM_CASE(128)
+    default: return hipErrorInvalidValue;
+    }
+#undef REM_CASE
+}
+
 // two cout tiles per wave (C = 64): nt position tiles per wave, 4 tile groups
 static hipError_t tower_dispatch_c2(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt, int grid, bool attr_only)
 {
@@ -2147,6 +2193,8 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         nn->c2 = 0;
     }
     hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true);
+    nn->use_rem = (nn->precision == 1 && nn->NTT == 7 && C >= 32 && !nn->mf32) ? 1 : 0;
+    if (he == hipSuccess && nn->use_rem) he = tower_dispatch_rem(nn, nullptr, TowerArgs(), 0, true);
     if (he == hipSuccess && nn->c2) he = tower_dispatch_c2(nn, nullptr, TowerArgs(), nn->NT_c2, 0, true);
 
     if (he == hipSuccess && nn->mf32) he = tower_dispatch_mf(nn, nullptr, TowerArgs(), 2, 0, true);
@@ -2205,8 +2253,10 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
         // as role 4) -- or stays with this launch if it is more than such a round holds
         ta.S_main = ta.S = nn->S_c2; ta.S_huge = nn->S;
         (void)tower_dispatch_c2(nn, s, ta, nn->NT_c2, (max_n + nn->S_c2 - 1) / nn->S_c2, false);
-        ta.role = 4; ta.S = nn->S;
-        (void)tower_dispatch(nn, s, ta, nn->NTT, nn->cus, false);
+        if (!nn->use_rem) {
+            ta.role = 4; ta.S = nn->S;
+            (void)tower_dispatch(nn, s, ta, nn->NTT, nn->cus, false);
+        }
     }
     if (nn->mf32 && !nn->c2) {
         // 32x32x16 tiling: main launch + one tail launch of half-size workgroups (same split rule, derived from n on the device)
@@ -2218,6 +2268,10 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
         }
     } else {
     if (!nn->c2) (void)tower_dispatch(nn, s, ta, nn->NTT, (max_n + nn->S - 1) / nn->S, false);
+    if (nn->use_rem) {     // the remainder sizes in one launch (the workgroups pick theirs)
+        ta.role = -1;
+        (void)tower_dispatch_rem(nn, s, ta, nn->cus, false);
+    } else {
     if (nn->S_small > 0) { // tail <= cus * S_small samples: one round of <2,2> workgroups
         ta.role = 1; ta.S = nn->S_small;
         (void)tower_dispatch(nn, s, ta, 2, nn->cus, false);
@@ -2229,6 +2283,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     if (nn->S_big > 0) {   // tail <= cus * S_big samples: one round of <5,5> workgroups
         ta.role = 3; ta.S = nn->S_big;
         (void)tower_dispatch(nn, s, ta, 5, nn->cus, false);
+    }
     }
     }
     static const bool no_fb = getenv("DBAZ_NO_FALLBACK") != nullptr; // measurement aid only
