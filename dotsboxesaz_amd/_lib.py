@@ -25,6 +25,7 @@ SYMBOLS = [
     "dbaz_get_counters", "dbaz_timing_begin", "dbaz_timing_end", "dbaz_fetch_samples", "dbaz_replay_rows_dev",
     "dbaz_replay_rows_clear", "dbaz_dataset_select", "dbaz_dataset_begin", "dbaz_dataset_add_rows", "dbaz_dataset_finish", "dbaz_dataset_fetch", "dbaz_dataset_batch",
     "dbaz_symmetry_apply", "dbaz_symmetry_table",
+    "dbaz_trainer_last_error", "dbaz_trainer_create", "dbaz_trainer_destroy", "dbaz_trainer_forward", "dbaz_trainer_backward",
 ]
 
 
@@ -117,9 +118,16 @@ def load():
     L.dbaz_timing_end.argtypes = [vp]
     L.dbaz_fetch_samples.argtypes = [vp, i32, vp] + [vp] * 13
     L.dbaz_replay_rows_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
+    L.dbaz_trainer_last_error.argtypes = [vp]
+    L.dbaz_trainer_last_error.restype = C.c_char_p
+    L.dbaz_trainer_create.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.dbaz_trainer_destroy.argtypes = [vp]
+    L.dbaz_trainer_destroy.restype = None
+    L.dbaz_trainer_forward.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.dbaz_trainer_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("dbaz_last_error", "dbaz_destroy"):
+        if name not in ("dbaz_last_error", "dbaz_destroy", "dbaz_trainer_last_error", "dbaz_trainer_destroy"):
             fn.restype = C.c_int
     _lib = L
     return L

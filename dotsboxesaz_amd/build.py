@@ -21,6 +21,7 @@ UNITS = [
     ("engine.hip", []),
     ("nn.hip", []),
     ("replay.hip", ["-ffp-contract=off"]),  # Kahan-compensated float64 means (pandas group_mean)
+    ("train.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

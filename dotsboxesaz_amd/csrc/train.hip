@@ -1,0 +1,741 @@
+// train.hip -- TRAINING-mode forward and backward of ResNetZero's residual tower on gfx950.
+//
+// Reference: ResBlock.forward (nn.py:48-57: relu(bn1(conv1(x))) -> bn2(conv2(.)) -> += x -> relu) under
+// model.train(True) inside NeuralNetWrapper.train (nn.py:203-221): BatchNorm2d normalises with the statistics of the
+// BATCH (biased variance), updates running_mean / running_var (momentum 0.1, unbiased variance), and
+// loss.backward() differentiates through those statistics.  The tower is 2*blocks conv3x3 (64 -> 64) layers, 98 % of the
+// step's FLOPs; bn_input / conv0 / the heads / the loss / SGD stay with the caller (train.py).
+//
+// Data layout: activations and gradients live in HBM as f32 NHWC -- row = sample * HW + position, 64 channels = 256 B per
+// row -- which is the row layout of the conv kernels' LDS images.  Per layer l (input A[l], l = 0 .. L-1):
+//   forward    Y[l]   = conv3x3(A[l]) + bias                         k_conv_t   (f16x3 MFMA, as the self-play tower)
+//              mean, invstd over the n*HW rows of Y[l]                k_colsum / k_bn_stats_fin (f64 sums)
+//              A[l+1] = relu(bn(Y[l]) (+ A[l-1] for the second conv of a block))   k_bn_apply
+//   backward   g = dA[l+1] * (A[l+1] > 0); sums of g and g*yhat      k_bn_bwd_sums / k_bn_bwd_fin (-> dgamma, dbeta)
+//              dY[l] = gamma*invstd*(g - mean(g) - yhat*mean(g*yhat)) k_bn_bwd_apply (also keeps g for the skip path)
+//              dW[l] = sum_rows A[l](row + tap) x dY[l](row)          k_wgrad (exact f32 MFMA) + k_wgrad_reduce
+//              dA[l] = conv3x3^T(dY[l]) (+ g of the block's end)      k_conv_t with flipped / transposed fragments
+// Every f32 operand of k_conv_t is an error-compensated (hi, lo) pair of halves scaled by a power of two taken from the
+// tensor's own maximum (tracked by the kernel that produced it), so gradients of any magnitude keep f32-grade products.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/dbaz.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+union u128h { f32x4 f; f16x8 h; };
+
+#define TT 512          // threads per workgroup of the conv / wgrad kernels: 8 waves, two per SIMD
+#define TC 64           // channels (the two-cout-tile MFMA tiling is written for 64)
+#define TL_MAX 64       // conv layers of a tower (2 * blocks)
+#define RED_BLOCKS 256  // workgroups of the column-sum kernels
+
+struct dbaz_trainer {
+    int dev = 0, H = 0, W = 0, HW = 0, L = 0, maxN = 0, n = 0;
+    int S = 1, Sw = 1, cus = 256;
+    float eps = 1e-5f, momentum = 0.1f;
+    size_t conv_lds = 0, wgrad_lds = 0;
+    bool have_fwd = false;
+    std::string err;
+    float *A = nullptr, *Y = nullptr, *G = nullptr, *dA[2] = {nullptr, nullptr}, *dY = nullptr;
+    _Float16 *wpk = nullptr;     // [2][L][C*C*9*2] halves: forward and transposed (dgrad) fragments
+    float *wsc = nullptr;        // [2][L] 2^-sw of the packed weights
+    unsigned *amax = nullptr;    // [L+1] bits of max|A[l]|, [L+1] = max|dY| of the layer in flight
+    float *mean = nullptr, *invstd = nullptr; // [L][C]
+    double *part = nullptr;      // [RED_BLOCKS][4][C] partial column sums
+    double *sums = nullptr;      // [4][C]
+    float *wg_part = nullptr;    // [cus][9][C][C]
+};
+
+static std::string g_train_error;
+
+static int terr(dbaz_trainer *t, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    (t ? t->err : g_train_error) = buf;
+    return code;
+}
+
+#define HIPCHK(t, call)                                                                                       \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) return terr(t, DBAZ_EDEVICE, "%s: %s", #call, hipGetErrorString(e_));          \
+    } while (0)
+
+// power of two that brings a tensor whose largest magnitude has the float bits `bits` into [2^13, 2^14)
+__device__ __forceinline__ float scale_from_max(unsigned bits)
+{
+    if (bits == 0u) return 1.0f;
+    int k = 13 - ((int)((bits >> 23) & 0xffu) - 127);
+    k = max(-100, min(100, k));
+    return __uint_as_float((unsigned)(k + 127) << 23);
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------
+// NCHW (torch) <-> NHWC rows; one workgroup per sample
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_nchw_to_rows(const float *__restrict__ in, float *__restrict__ out, int HW, unsigned *amax)
+{
+    extern __shared__ float sm[]; // [C][HW + 1]
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const float *src = in + (size_t)s * TC * HW;
+    float mx = 0.0f;
+    for (int i = tid; i < TC * HW; i += 256) {
+        const int c = i / HW, p = i - c * HW;
+        const float v = src[i];
+        mx = fmaxf(mx, fabsf(v));
+        sm[c * (HW + 1) + p] = v;
+    }
+    __syncthreads();
+    float *dst = out + (size_t)s * HW * TC;
+    for (int i = tid; i < TC * HW; i += 256) {
+        const int p = i >> 6, c = i & 63;
+        dst[i] = sm[c * (HW + 1) + p];
+    }
+    if (amax) {
+        mx = wave_max(mx);
+        if ((tid & 63) == 0 && mx > 0.0f) atomicMax(amax, __float_as_uint(mx));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rows_to_nchw(const float *__restrict__ in, float *__restrict__ out, int HW)
+{
+    extern __shared__ float sm[]; // [HW][C + 1]
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const float *src = in + (size_t)s * HW * TC;
+    for (int i = tid; i < TC * HW; i += 256) sm[(i >> 6) * (TC + 1) + (i & 63)] = src[i];
+    __syncthreads();
+    float *dst = out + (size_t)s * TC * HW;
+    for (int i = tid; i < TC * HW; i += 256) {
+        const int c = i / HW, p = i - c * HW;
+        dst[i] = sm[p * (TC + 1) + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// weights [cout][cin][3][3] f32 (torch) -> (hi, lo) MFMA fragments [ct][tap][ks][hi|lo][lane][8 halves], scaled by 2^sw
+// with max|w| * 2^sw in [2^13, 2^14) (the layout nn.hip's pack_conv builds on the host).  blockIdx.y = 1 packs the
+// transposed convolution of the backward pass: out channel = cin, in channel = cout, tap flipped.
+// ------------------------------------------------------------------------------------
+struct PackArgs { const float *w[TL_MAX]; };
+
+__global__ void __launch_bounds__(TT) k_pack_w(PackArgs pa, _Float16 *__restrict__ wpk, float *__restrict__ wsc, int L)
+{
+    __shared__ float red[TT / 64];
+    __shared__ float s_scale;
+    const int l = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const float *w = pa.w[l];
+    constexpr int NW = TC * TC * 9;
+    float mx = 0.0f;
+    for (int i = tid; i < NW; i += TT) mx = fmaxf(mx, fabsf(w[i]));
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        float m = 0.0f;
+        for (int i = 0; i < TT / 64; i++) m = fmaxf(m, red[i]);
+        const float sc = scale_from_max(__float_as_uint(m));
+        s_scale = sc;
+        wsc[dir * L + l] = 1.0f / sc;
+    }
+    __syncthreads();
+    const float sc = s_scale;
+    _Float16 *o = wpk + ((size_t)dir * L + l) * NW * 2;
+    constexpr int KS = TC / 32;
+    for (int i = tid; i < NW; i += TT) {
+        // i = (((ct * 9 + tap) * KS + ks) * 64 + lane) * 8 + e
+        const int e = i & 7, lane = (i >> 3) & 63, r = i >> 9, ks = r % KS, r2 = r / KS, tap = r2 % 9, ct = r2 / 9;
+        const int oc = ct * 16 + (lane & 15), ic = ks * 32 + 8 * (lane >> 4) + e;
+        const float v = (dir == 0 ? w[((size_t)oc * TC + ic) * 9 + tap] : w[((size_t)ic * TC + oc) * 9 + (8 - tap)]) * sc;
+        const _Float16 h = (_Float16)v;
+        const size_t base = ((size_t)r * 2) * 64 * 8 + (size_t)lane * 8 + e;
+        o[base] = h;
+        o[base + 64 * 8] = (_Float16)(v - (float)h);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// conv3x3 64 -> 64 over NHWC rows, f16x3 on v_mfma_f32_16x16x32_f16 with two cout tiles per wave (the tiling of
+// nn.hip's conv_lds_h3_c2): a workgroup stages the S samples' rows as (hi, lo) halves in an LDS image of (C+8)-dword rows,
+// wave w owns couts [32 (w & 1), +32) and position tiles [4 (w >> 1), +4); out-of-image taps read a zero region at the
+// lane's own bank slot.  out = acc * 2^-(sx+sw) (+ bias) (+ add).
+// ------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float *in;          // [n*HW][C]
+    const unsigned *in_max;   // bits of max|in|
+    const _Float16 *wpk;      // this layer's fragments
+    const float *wsc;         // this layer's 2^-sw
+    const float *bias;        // [C] or nullptr
+    const float *add;         // [n*HW][C] added to the result, or nullptr
+    float *out;               // [n*HW][C]
+    int n, S, H, W;
+};
+
+struct WPre { f32x4 h0, l0, h1, l1; };
+
+__global__ void __launch_bounds__(TT, 1) k_conv_t(ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int C = TC, S4 = (C + 8) / 4, KS = C / 32, LO = C / 8, N = 9 * KS, NTT = 4;
+    const int HW = a.H * a.W, W = a.W, H = a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s0 = blockIdx.x * a.S;
+    const int ns = min(a.S, a.n - s0);
+    if (ns <= 0) return;
+    const int R = ns * HW;
+    const int zu = (a.S * HW * S4 + 15) & ~15;
+    f32x4 *X4 = reinterpret_cast<f32x4 *>(lds);
+    const f32x4 *wpk = reinterpret_cast<const f32x4 *>(a.wpk);
+    const int ct0 = (wave & 1) * 2;
+    WPre pre[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const f32x4 *wb = wpk + (size_t)(ct0 + c) * N * 2 * 64 + lane;
+        pre[c].h0 = wb[0]; pre[c].l0 = wb[64]; pre[c].h1 = wb[128]; pre[c].l1 = wb[192];
+    }
+    const float sx = scale_from_max(*a.in_max);
+    {
+        const f32x4 *in4 = reinterpret_cast<const f32x4 *>(a.in) + (size_t)s0 * HW * (C / 4);
+        _Float16 *img = reinterpret_cast<_Float16 *>(lds);
+        for (int i = tid; i < R * (C / 4); i += TT) {
+            const int row = i >> 4, c4 = i & 15;
+            const f32x4 v = in4[i] * sx;
+            union { h2v h[2]; u32x2 u; } oh, ol;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const f2v x = {v[2 * q], v[2 * q + 1]};
+                const h2v h = __builtin_convertvector(x, h2v);
+                oh.h[q] = h;
+                ol.h[q] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
+            }
+            _Float16 *ph = img + (size_t)row * (S4 * 8) + c4 * 4;
+            *reinterpret_cast<u32x2 *>(ph) = oh.u;
+            *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
+        }
+        if (tid < 3 * S4) X4[zu + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int jrow = lane & 15, gq = lane >> 4;
+    const int tbase = (wave >> 1) * NTT;
+    int vm[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; t++) {
+        const int row = (tbase + t) * 16 + jrow;
+        const int pos = row % HW, y = pos / W, x = pos - y * W;
+        int m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
+        }
+        vm[t] = row < R ? m : 0;
+    }
+    const int rowbase = (tbase * 16 + jrow) * S4 + gq;
+    const int zbase = zu;
+    f32x4 acc[2][NTT];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int t = 0; t < NTT; t++) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 *wb0 = wpk + (size_t)ct0 * N * 2 * 64 + lane;
+    const f32x4 *wb1 = wb0 + (size_t)N * 2 * 64;
+    u128h a_h[2][3], a_l[2][3];
+    u128h bh[NTT], bl[NTT];
+    const char *sb = reinterpret_cast<const char *>(lds);
+    int ab[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; t++)
+        ab[t] = ((vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4) * 16;
+#pragma unroll
+    for (int c = 0; c < 2; c++) { a_h[c][0].f = pre[c].h0; a_l[c][0].f = pre[c].l0; a_h[c][1].f = pre[c].h1; a_l[c][1].f = pre[c].l1; }
+#pragma unroll
+    for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4);
+#pragma unroll
+    for (int t = 0; t < NTT; t++) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + LO * 16);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int cur = i % 3, nxt = (i + 2) % 3;
+        const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
+        if (i + 2 < N) {
+            a_h[0][nxt].f = wb0[(size_t)(i + 2) * 128];
+            a_l[0][nxt].f = wb0[(size_t)(i + 2) * 128 + 64];
+            a_h[1][nxt].f = wb1[(size_t)(i + 2) * 128];
+            a_l[1][nxt].f = wb1[(size_t)(i + 2) * 128 + 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[0][cur].h, bh[t].h, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[1][cur].h, bh[t].h, acc[1][t], 0, 0, 0);
+        }
+        if (ni < N && nks == 0) {
+            const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
+            const int zt = zbase + ((rowbase + off) & 15);
+#pragma unroll
+            for (int t = 0; t < NTT; t++) ab[t] = (((vm[t] >> ntap) & 1) ? rowbase + off : zt - t * 16 * S4) * 16;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[0][cur].h, bh[t].h, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[1][cur].h, bh[t].h, acc[1][t], 0, 0, 0);
+            if (ni < N) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[0][cur].h, bl[t].h, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[1][cur].h, bl[t].h, acc[1][t], 0, 0, 0);
+            if (ni < N) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64 + LO * 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- epilogue: lane holds couts (ct0 + c) * 16 + 4 gq .. +3 of position row (tbase + t) * 16 + jrow
+    const float osc = (1.0f / sx) * *a.wsc;
+    f32x4 *out4 = reinterpret_cast<f32x4 *>(a.out) + (size_t)s0 * HW * (C / 4);
+    const f32x4 *add4 = a.add ? reinterpret_cast<const f32x4 *>(a.add) + (size_t)s0 * HW * (C / 4) : nullptr;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int cq = (ct0 + c) * 4 + gq;
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            const int row = (tbase + t) * 16 + jrow;
+            if (row < R) {
+                f32x4 v = acc[c][t] * osc + bv;
+                if (add4) v += add4[(size_t)row * (C / 4) + cq];
+                out4[(size_t)row * (C / 4) + cq] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// column sums over the rows of [M][C] tensors, f64: the workgroup's 512 threads = 32 row lanes x 16 channel quads
+// ------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void block_colsum_store(double (&s)[K][4], double *part /*[blocks][K][C]*/)
+{
+    __shared__ double red[TT / 16][K][4 * 16 + 1];
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) red[rl][k][cq * 4 + e] = s[k][e];
+    __syncthreads();
+    if (tid < K * TC) {
+        const int k = tid / TC, c = tid - k * TC;
+        double v = 0.0;
+        for (int r = 0; r < TT / 16; r++) v += red[r][k][c];
+        part[((size_t)blockIdx.x * K + k) * TC + c] = v;
+    }
+}
+
+// partials of sum(y) and sum(y^2)
+__global__ void __launch_bounds__(TT) k_colsum_y(const f32x4 *__restrict__ y4, long long M, double *part)
+{
+    double s[2][4] = {};
+    const int cq = threadIdx.x & 15;
+    for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += (long long)gridDim.x * 32) {
+        const f32x4 v = y4[r * 16 + cq];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const double d = v[e]; s[0][e] += d; s[1][e] += d * d; }
+    }
+    block_colsum_store<2>(s, part);
+}
+
+// final sums -> batch mean / invstd, running statistics (BatchNorm2d training mode: momentum 0.1, unbiased running variance)
+__global__ void __launch_bounds__(TC) k_bn_stats_fin(const double *part, int nparts, long long M, float eps, float momentum,
+                                                     float *mean, float *invstd, float *run_mean, float *run_var)
+{
+    const int c = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nparts; b++) { s += part[((size_t)b * 2 + 0) * TC + c]; q += part[((size_t)b * 2 + 1) * TC + c]; }
+    const double m = s / (double)M;
+    double var = q / (double)M - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + (double)momentum * m);
+    if (run_var) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + (double)momentum * unb);
+    }
+}
+
+// A_out = relu(gamma * (y - mean) * invstd + beta (+ res)); tracks max(A_out)
+__global__ void __launch_bounds__(256) k_bn_apply(const f32x4 *__restrict__ y4, const f32x4 *__restrict__ res4, f32x4 *__restrict__ out4,
+                                                  long long n4, const float *mean, const float *invstd, const float *gamma,
+                                                  const float *beta, unsigned *amax)
+{
+    const int cq = threadIdx.x & 15; // (blockDim and the grid stride are multiples of 16)
+    const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cq * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(invstd + cq * 4) * *reinterpret_cast<const f32x4 *>(gamma + cq * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + cq * 4);
+    float mx = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 v = (y4[i] - mu) * sc + be;
+        if (res4) v += res4[i];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[e] = fmaxf(v[e], 0.0f); mx = fmaxf(mx, v[e]); }
+        out4[i] = v;
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(amax, __float_as_uint(mx));
+}
+
+// backward, pass 1: g = dA * (A_out > 0); partials of sum(g) and sum(g * yhat)
+__global__ void __launch_bounds__(TT) k_bn_bwd_sums(const f32x4 *__restrict__ dA4, const f32x4 *__restrict__ aout4, const f32x4 *__restrict__ y4,
+                                                    long long M, const float *mean, const float *invstd, double *part)
+{
+    double s[2][4] = {};
+    const int cq = threadIdx.x & 15;
+    const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cq * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + cq * 4);
+    for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += (long long)gridDim.x * 32) {
+        const f32x4 d = dA4[r * 16 + cq], ao = aout4[r * 16 + cq], y = y4[r * 16 + cq];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float g = ao[e] > 0.0f ? d[e] : 0.0f;
+            const float yh = (y[e] - mu[e]) * is[e];
+            s[0][e] += (double)g;
+            s[1][e] += (double)g * (double)yh;
+        }
+    }
+    block_colsum_store<2>(s, part);
+}
+
+// final sums of K quantities; out_a / out_b (optional) receive sums 0 / 1 as f32 (dbeta, dgamma); zero = word to clear
+template <int K>
+__global__ void __launch_bounds__(TC) k_sums_fin(const double *part, int nparts, double *sums, float *out0, float *out1, unsigned *zero)
+{
+    const int c = threadIdx.x;
+    for (int k = 0; k < K; k++) {
+        double s = 0.0;
+        for (int b = 0; b < nparts; b++) s += part[((size_t)b * K + k) * TC + c];
+        if (sums) sums[k * TC + c] = s;
+        if (k == 0 && out0) out0[c] = (float)s;
+        if (k == 1 && out1) out1[c] = (float)s;
+    }
+    if (zero && c == 0) *zero = 0u;
+}
+
+// backward, pass 2: dY = gamma * invstd * (g - sum(g)/M - yhat * sum(g*yhat)/M); keeps g (skip path of a block's end);
+// tracks max|dY|; partials of sum(dY) (the conv bias gradient)
+__global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ dA4, const f32x4 *__restrict__ aout4, const f32x4 *__restrict__ y4,
+                                                     long long M, const float *mean, const float *invstd, const float *gamma,
+                                                     const double *sums, f32x4 *__restrict__ dY4, f32x4 *__restrict__ g4,
+                                                     unsigned *amax, double *part)
+{
+    double s[1][4] = {};
+    const int cq = threadIdx.x & 15;
+    const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cq * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + cq * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + cq * 4);
+    f32x4 mg, mgy;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        mg[e] = (float)(sums[cq * 4 + e] / (double)M);
+        mgy[e] = (float)(sums[TC + cq * 4 + e] / (double)M);
+    }
+    float mx = 0.0f;
+    for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += (long long)gridDim.x * 32) {
+        const f32x4 d = dA4[r * 16 + cq], ao = aout4[r * 16 + cq], y = y4[r * 16 + cq];
+        f32x4 g, o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            g[e] = ao[e] > 0.0f ? d[e] : 0.0f;
+            const float yh = (y[e] - mu[e]) * is[e];
+            o[e] = ga[e] * is[e] * (g[e] - mg[e] - yh * mgy[e]);
+            mx = fmaxf(mx, fabsf(o[e]));
+            s[0][e] += (double)o[e];
+        }
+        dY4[r * 16 + cq] = o;
+        if (g4) g4[r * 16 + cq] = g;
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(amax, __float_as_uint(mx));
+    block_colsum_store<1>(s, part);
+}
+
+// ------------------------------------------------------------------------------------
+// weight gradient dW[tap][cin][cout] = sum over rows of A(row + tap offset)[cin] * dY(row)[cout], exact f32 on
+// v_mfma_f32_16x16x4_f32 (m = cin, n = cout, k = 4 consecutive rows).  A workgroup stages chunks of Sw samples (both
+// tensors, f32 rows of C+16 dwords: the two rows of a 32-lane read group fall on disjoint banks) and keeps the whole
+// 9 x 64 x 64 gradient in registers: wave w owns cin tile w & 3 and cout tiles 2 (w >> 2), +1 for all 9 taps (18
+// accumulator tiles); the workgroups' partial gradients are summed by k_wgrad_reduce.
+// ------------------------------------------------------------------------------------
+#define WG_STRIDE (TC + 16)
+
+__global__ void __launch_bounds__(TT, 1) k_wgrad(const float *__restrict__ act, const float *__restrict__ dy, int n, int Sw, int H, int W,
+                                                 float *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int HW = H * W;
+    const int RW = (Sw * HW + 3) & ~3; // rows per chunk, padded to the K step
+    float *Ai = lds;
+    float *Di = lds + (size_t)RW * WG_STRIDE;
+    unsigned short *mask = reinterpret_cast<unsigned short *>(Di + (size_t)RW * WG_STRIDE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cit = wave & 3, ch = wave >> 2;
+    const int m16 = lane & 15, gq = lane >> 4;
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; t++) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int r = tid; r < RW; r += TT) {
+        const int pos = r % HW, y = pos / W, x = pos - y * W;
+        int m = 0;
+        for (int tap = 0; tap < 9; tap++) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
+        }
+        mask[r] = (unsigned short)m;
+    }
+    const int nchunks = (n + Sw - 1) / Sw;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int s0 = chunk * Sw, ns = min(Sw, n - s0), R = ns * HW;
+        __syncthreads(); // the previous chunk's reads are done
+        {
+            const f32x4 *a4 = reinterpret_cast<const f32x4 *>(act) + (size_t)s0 * HW * 16;
+            const f32x4 *d4 = reinterpret_cast<const f32x4 *>(dy) + (size_t)s0 * HW * 16;
+            for (int i = tid; i < RW * 16; i += TT) {
+                const int row = i >> 4, c4 = i & 15;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(Ai + (size_t)row * WG_STRIDE + c4 * 4) = row < R ? a4[i] : z;
+                *reinterpret_cast<f32x4 *>(Di + (size_t)row * WG_STRIDE + c4 * 4) = row < R ? d4[i] : z;
+            }
+        }
+        __syncthreads();
+        const float *ab = Ai + cit * 16 + m16;
+        const float *db = Di + ch * 32 + m16;
+#pragma unroll 2
+        for (int k0 = 0; k0 < RW; k0 += 4) {
+            const int r = k0 + gq;
+            const int m = mask[r];
+            const float b0 = db[(size_t)r * WG_STRIDE], b1 = db[(size_t)r * WG_STRIDE + 16];
+            float av[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const int rr = min(max(r + (tap / 3 - 1) * W + (tap % 3 - 1), 0), RW - 1);
+                const float v = ab[(size_t)rr * WG_STRIDE];
+                av[tap] = ((m >> tap) & 1) ? v : 0.0f;
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], b0, acc[tap][0], 0, 0, 0);
+                acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], b1, acc[tap][1], 0, 0, 0);
+            }
+        }
+    }
+    // lane holds dW[tap][cin = cit*16 + 4 gq + i][cout = (2 ch + j)*16 + m16]
+    float *o = part + (size_t)blockIdx.x * 9 * TC * TC;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                o[((size_t)tap * TC + cit * 16 + 4 * gq + i) * TC + (2 * ch + j) * 16 + m16] = acc[tap][j][i];
+}
+
+// sums the workgroups' partial gradients (f64) and writes torch's [cout][cin][3][3]
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ part, int nparts, float *__restrict__ dw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x; // (tap * C + cin) * C + cout
+    if (i >= 9 * TC * TC) return;
+    double s = 0.0;
+    for (int b = 0; b < nparts; b++) s += (double)part[(size_t)b * 9 * TC * TC + i];
+    const int co = i & 63, ci = (i >> 6) & 63, tap = i >> 12;
+    dw[((size_t)co * TC + ci) * 9 + tap] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+static size_t act_elems(const dbaz_trainer *t) { return (size_t)t->maxN * t->HW * TC; }
+
+extern "C" const char *dbaz_trainer_last_error(const dbaz_trainer *t) { return t ? t->err.c_str() : g_train_error.c_str(); }
+
+extern "C" void dbaz_trainer_destroy(dbaz_trainer *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->dev);
+    void *ptrs[] = {t->A, t->Y, t->G, t->dA[0], t->dA[1], t->dY, t->wpk, t->wsc, t->amax, t->mean, t->invstd, t->part, t->sums, t->wg_part};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete t;
+}
+
+extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels, int32_t blocks, int32_t max_batch, int32_t device,
+                                   dbaz_trainer **out)
+{
+    if (!out) return terr(nullptr, DBAZ_EINVAL, "null argument");
+    *out = nullptr;
+    if (channels != TC) return terr(nullptr, DBAZ_EINVAL, "the training tower is built for %d channels (got %d)", TC, channels);
+    if (rows < 1 || cols < 1 || (rows + 1) * (cols + 1) > 196) return terr(nullptr, DBAZ_EINVAL, "board %dx%d unsupported", rows, cols);
+    if (blocks < 1 || 2 * blocks > TL_MAX) return terr(nullptr, DBAZ_EINVAL, "blocks must be in 1..%d", TL_MAX / 2);
+    if (max_batch < 1) return terr(nullptr, DBAZ_EINVAL, "max_batch must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return terr(nullptr, DBAZ_EDEVICE, "no HIP device %d", device);
+    dbaz_trainer *t = new dbaz_trainer();
+    t->dev = device; t->H = rows + 1; t->W = cols + 1; t->HW = t->H * t->W; t->L = 2 * blocks; t->maxN = max_batch;
+    if (hipSetDevice(device) != hipSuccess) { delete t; return terr(nullptr, DBAZ_EDEVICE, "hipSetDevice(%d) failed", device); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) t->cus = prop.multiProcessorCount;
+    t->S = 256 / t->HW;
+    t->Sw = 196 / t->HW;
+    {
+        const int S4 = (TC + 8) / 4;
+        const int zu = (t->S * t->HW * S4 + 15) & ~15;
+        t->conv_lds = (size_t)(zu + 3 * S4) * 16;
+        const int RW = (t->Sw * t->HW + 3) & ~3;
+        t->wgrad_lds = (size_t)RW * WG_STRIDE * 4 * 2 + (size_t)((RW + 7) & ~7) * 2;
+    }
+    const size_t ae = act_elems(t);
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    alloc((void **)&t->A, ae * (t->L + 1) * 4);
+    alloc((void **)&t->Y, ae * t->L * 4);
+    alloc((void **)&t->G, ae * 4);
+    alloc((void **)&t->dA[0], ae * 4);
+    alloc((void **)&t->dA[1], ae * 4);
+    alloc((void **)&t->dY, ae * 4);
+    alloc((void **)&t->wpk, (size_t)2 * t->L * TC * TC * 9 * 2 * sizeof(_Float16));
+    alloc((void **)&t->wsc, (size_t)2 * t->L * 4);
+    alloc((void **)&t->amax, (size_t)(t->L + 2) * 4);
+    alloc((void **)&t->mean, (size_t)t->L * TC * 4);
+    alloc((void **)&t->invstd, (size_t)t->L * TC * 4);
+    alloc((void **)&t->part, (size_t)RED_BLOCKS * 4 * TC * 8);
+    alloc((void **)&t->sums, (size_t)4 * TC * 8);
+    alloc((void **)&t->wg_part, (size_t)t->cus * 9 * TC * TC * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_lds);
+    if (e != hipSuccess) {
+        const std::string msg = hipGetErrorString(e);
+        dbaz_trainer_destroy(t);
+        return terr(nullptr, DBAZ_EDEVICE, "trainer allocation failed: %s", msg.c_str());
+    }
+    *out = t;
+    return DBAZ_OK;
+}
+
+static int red_blocks(long long M) { return (int)std::max(1LL, std::min((long long)RED_BLOCKS, (M + 31) / 32)); }
+
+// Training-mode forward of the tower.  x / out: DEVICE float32 [n][64][H][W] (torch NCHW); conv_w[l] [64][64][3][3],
+// conv_b[l], bn_w[l], bn_b[l], run_mean[l], run_var[l] [64]: DEVICE pointers of layer l = 2*block + (0: conv1/bn1, 1:
+// conv2/bn2); the running statistics are updated in place.  Asynchronous on `stream`.
+extern "C" int dbaz_trainer_forward(dbaz_trainer *t, int32_t n, const float *x, const float *const *conv_w, const float *const *conv_b,
+                                    const float *const *bn_w, const float *const *bn_b, float *const *run_mean, float *const *run_var,
+                                    float *out, void *stream)
+{
+    if (!t) return DBAZ_EINVAL;
+    if (n < 1 || n > t->maxN) return terr(t, DBAZ_EINVAL, "batch %d outside 1..%d", n, t->maxN);
+    if (!x || !out || !conv_w || !conv_b || !bn_w || !bn_b) return terr(t, DBAZ_EINVAL, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(t, hipSetDevice(t->dev));
+    const int L = t->L, HW = t->HW;
+    const size_t ae = act_elems(t);
+    const long long M = (long long)n * HW;
+    t->have_fwd = false;
+    HIPCHK(t, hipMemsetAsync(t->amax, 0, (size_t)(L + 2) * 4, s));
+    hipLaunchKernelGGL(k_nchw_to_rows, dim3(n), dim3(256), (size_t)TC * (HW + 1) * 4, s, x, t->A, HW, t->amax);
+    PackArgs pa;
+    for (int l = 0; l < L; l++) pa.w[l] = conv_w[l];
+    hipLaunchKernelGGL(k_pack_w, dim3(L, 2), dim3(TT), 0, s, pa, t->wpk, t->wsc, L);
+    const int grid = (n + t->S - 1) / t->S;
+    const int rb = red_blocks(M);
+    const long long n4 = M * 16;
+    const int ab = (int)std::min<long long>((n4 + 255) / 256, 4096);
+    for (int l = 0; l < L; l++) {
+        ConvArgs ca;
+        ca.in = t->A + ae * l; ca.in_max = t->amax + l;
+        ca.wpk = t->wpk + (size_t)l * TC * TC * 9 * 2; ca.wsc = t->wsc + l;
+        ca.bias = conv_b[l]; ca.add = nullptr; ca.out = t->Y + ae * l;
+        ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
+        hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        hipLaunchKernelGGL(k_colsum_y, dim3(rb), dim3(TT), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l), M, t->part);
+        hipLaunchKernelGGL(k_bn_stats_fin, dim3(1), dim3(TC), 0, s, t->part, rb, M, t->eps, t->momentum, t->mean + l * TC,
+                           t->invstd + l * TC, run_mean ? run_mean[l] : nullptr, run_var ? run_var[l] : nullptr);
+        hipLaunchKernelGGL(k_bn_apply, dim3(ab), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l),
+                           (l & 1) ? reinterpret_cast<const f32x4 *>(t->A + ae * (l - 1)) : nullptr,
+                           reinterpret_cast<f32x4 *>(t->A + ae * (l + 1)), n4, t->mean + l * TC, t->invstd + l * TC, bn_w[l], bn_b[l],
+                           t->amax + l + 1);
+    }
+    hipLaunchKernelGGL(k_rows_to_nchw, dim3(n), dim3(256), (size_t)HW * (TC + 1) * 4, s, t->A + ae * L, out, HW);
+    HIPCHK(t, hipGetLastError());
+    t->n = n;
+    t->have_fwd = true;
+    return DBAZ_OK;
+}
+
+// Backward of the forward pass still held by the handle.  grad_out / grad_x: DEVICE [n][64][H][W]; the parameter gradients
+// are written (not accumulated) to g_conv_w[l] [64][64][3][3], g_conv_b[l], g_bn_w[l], g_bn_b[l] [64].  conv_w / bn_w: the
+// same pointers as in the forward call.  Asynchronous on `stream`.
+extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, const float *const *bn_w, float *grad_x,
+                                     float *const *g_conv_w, float *const *g_conv_b, float *const *g_bn_w, float *const *g_bn_b,
+                                     void *stream)
+{
+    if (!t) return DBAZ_EINVAL;
+    if (!t->have_fwd) return terr(t, DBAZ_ESTATE, "dbaz_trainer_backward without a forward pass");
+    if (!grad_out || !grad_x || !bn_w || !g_conv_w || !g_conv_b || !g_bn_w || !g_bn_b) return terr(t, DBAZ_EINVAL, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(t, hipSetDevice(t->dev));
+    const int L = t->L, HW = t->HW, n = t->n;
+    const size_t ae = act_elems(t);
+    const long long M = (long long)n * HW;
+    const int grid = (n + t->S - 1) / t->S;
+    const int rb = red_blocks(M);
+    const int nchunks = (n + t->Sw - 1) / t->Sw;
+    const int wg = std::min(t->cus, nchunks);
+    unsigned *dymax = t->amax + L + 1;
+    int cur = 0;
+    hipLaunchKernelGGL(k_nchw_to_rows, dim3(n), dim3(256), (size_t)TC * (HW + 1) * 4, s, grad_out, t->dA[cur], HW, (unsigned *)nullptr);
+    for (int l = L - 1; l >= 0; l--) {
+        const f32x4 *dA4 = reinterpret_cast<const f32x4 *>(t->dA[cur]);
+        const f32x4 *ao4 = reinterpret_cast<const f32x4 *>(t->A + ae * (l + 1));
+        const f32x4 *y4 = reinterpret_cast<const f32x4 *>(t->Y + ae * l);
+        hipLaunchKernelGGL(k_bn_bwd_sums, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, t->part);
+        hipLaunchKernelGGL((k_sums_fin<2>), dim3(1), dim3(TC), 0, s, t->part, rb, t->sums, g_bn_b[l], g_bn_w[l], dymax);
+        hipLaunchKernelGGL(k_bn_bwd_apply, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, bn_w[l],
+                           t->sums, reinterpret_cast<f32x4 *>(t->dY), (l & 1) ? reinterpret_cast<f32x4 *>(t->G) : (f32x4 *)nullptr,
+                           dymax, t->part);
+        hipLaunchKernelGGL((k_sums_fin<1>), dim3(1), dim3(TC), 0, s, t->part, rb, (double *)nullptr, g_conv_b[l], (float *)nullptr,
+                           (unsigned *)nullptr);
+        hipLaunchKernelGGL(k_wgrad, dim3(wg), dim3(TT), t->wgrad_lds, s, t->A + ae * l, t->dY, n, t->Sw, t->H, t->W, t->wg_part);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((9 * TC * TC + 255) / 256), dim3(256), 0, s, t->wg_part, wg, g_conv_w[l]);
+        ConvArgs ca;
+        ca.in = t->dY; ca.in_max = dymax;
+        ca.wpk = t->wpk + ((size_t)L + l) * TC * TC * 9 * 2; ca.wsc = t->wsc + L + l;
+        ca.bias = nullptr; ca.out = t->dA[1 - cur];
+        ca.add = (l & 1) ? nullptr : t->G; // the input of a block's first conv is also the block's skip input: + g of its end
+        ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
+        hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        cur = 1 - cur;
+    }
+    hipLaunchKernelGGL(k_rows_to_nchw, dim3(n), dim3(256), (size_t)HW * (TC + 1) * 4, s, t->dA[cur], grad_x, HW);
+    HIPCHK(t, hipGetLastError());
+    t->have_fwd = false;
+    return DBAZ_OK;
+}

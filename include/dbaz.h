@@ -258,6 +258,29 @@ int dbaz_symmetry_apply(dbaz_engine *e, int32_t sym, const float *boards_in_dev,
 /* host only (no handle, no GPU): src[a'] with out[a'] = in[src[a']] over the two edge planes */
 int dbaz_symmetry_table(int32_t rows, int32_t cols, int32_t sym, int32_t *lut_out);
 
+/* ---- training-mode tower: forward and backward of ResNetZero's residual blocks under model.train(True) ----
+ * Replaces, inside NeuralNetWrapper.train's step (nn.py:203-221: p, v = self.model(boards); loss.backward()), the
+ * ResBlock stack of ResNet.forward (nn.py:23-28,48-57) with BatchNorm2d in training mode (batch statistics, running-stat
+ * update, gradient through the statistics) -- 98 % of the step's FLOPs.  bn_input, conv0, the heads, AlphaZeroLoss and
+ * torch.optim.SGD stay with the caller.  All tensor arguments are DEVICE pointers; calls are asynchronous on `stream`
+ * (a hipStream_t, NULL = the default stream).  One handle holds the activations of ONE forward pass for its backward. */
+typedef struct dbaz_trainer dbaz_trainer;
+const char *dbaz_trainer_last_error(const dbaz_trainer *t); /* t == NULL: why dbaz_trainer_create failed */
+int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels /* 64 */, int32_t blocks, int32_t max_batch,
+                        int32_t device, dbaz_trainer **out);
+void dbaz_trainer_destroy(dbaz_trainer *t);
+/* x / out: float32 [n][64][H][W] (torch NCHW).  conv_w[l] [64][64][3][3], conv_b[l], bn_w[l], bn_b[l], run_mean[l],
+ * run_var[l] [64]: HOST arrays of DEVICE pointers, layer l = 2*block + (0: conv1/bn1, 1: conv2/bn2); run_mean / run_var
+ * are updated in place (momentum 0.1, unbiased variance), NULL skips that. */
+int dbaz_trainer_forward(dbaz_trainer *t, int32_t n, const float *x, const float *const *conv_w, const float *const *conv_b,
+                         const float *const *bn_w, const float *const *bn_b, float *const *run_mean, float *const *run_var,
+                         float *out, void *stream);
+/* backward of the forward pass the handle holds: grad_out / grad_x [n][64][H][W]; parameter gradients are WRITTEN to
+ * g_conv_w[l], g_conv_b[l], g_bn_w[l], g_bn_b[l] (shapes of the parameters); bn_w as in the forward call */
+int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, const float *const *bn_w, float *grad_x,
+                          float *const *g_conv_w, float *const *g_conv_b, float *const *g_bn_w, float *const *g_bn_b,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,159 @@
+"""Training-mode residual tower on HIP (csrc/train.hip, dbaz_trainer_*) against torch autograd.
+
+Ground truth = the same blocks (oracle/nn_ref._Block: nn.py:33-58 restated) evaluated by torch in FLOAT64 on the CPU in
+train mode; the HIP path works in f32 (f16x3 MFMA products, f64 statistics), so it is compared with a tolerance relative
+to each tensor's largest magnitude and, beside it, with torch's own float32 result: the HIP path must be as close to the
+float64 truth as torch float32 is (within a small factor).  Parity status: torch restatement of the reference's blocks --
+the reference's own training goldens (tests/golden/train_*.npz) are covered by test_hip_train_step below through
+train.train()."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def make_blocks(nb, seed):
+    torch.manual_seed(seed)
+    blocks = torch.nn.Sequential(*[nn_ref._Block(64, 3) for _ in range(nb)])
+    g = torch.Generator().manual_seed(seed + 1)
+    for m in blocks.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = torch.rand(64, generator=g) + 0.5
+            m.bias.data = torch.randn(64, generator=g) * 0.2
+            m.running_mean.data = torch.randn(64, generator=g) * 0.1
+            m.running_var.data = torch.rand(64, generator=g) + 0.5
+    return blocks
+
+
+def run_torch(blocks, x, gout, dtype):
+    b = copy.deepcopy(blocks).to(dtype)
+    b.train(True)
+    xx = x.to(dtype).clone().requires_grad_(True)
+    out = b(xx)
+    out.backward(gout.to(dtype))
+    grads = {k: p.grad.double() for k, p in b.named_parameters()}
+    stats = {k: v.double() for k, v in b.state_dict().items() if "running" in k}
+    return out.detach().double(), xx.grad.double(), grads, stats
+
+
+def run_hip(blocks, x, gout):
+    from dotsboxesaz_amd import train_tower
+
+    class M:  # the container shape train_tower expects: model.resnet.resblocks / conv0
+        pass
+    b = copy.deepcopy(blocks).cuda()
+    b.train(True)
+    m = M()
+    m.resnet = M()
+    m.resnet.resblocks = b
+    m.resnet.conv0 = torch.nn.Conv2d(3, 64, 3)
+    xx = x.cuda().clone().requires_grad_(True)
+    assert train_tower.supported(m, xx)
+    out = train_tower.resblocks_forward(m, xx)
+    out.backward(gout.cuda())
+    torch.cuda.synchronize()
+    grads = {k: p.grad.double().cpu() for k, p in b.named_parameters()}
+    stats = {k: v.double().cpu() for k, v in b.state_dict().items() if "running" in k}
+    nbt = [int(v) for k, v in b.state_dict().items() if "num_batches_tracked" in k]
+    return out.detach().double().cpu(), xx.grad.double().cpu(), grads, stats, nbt
+
+
+def relu_margins(blocks, x):
+    """per sample: the smallest |pre-activation| any ReLU of the float64 reference sees.  An element within rounding
+    distance of 0 can come out on the other side of the ReLU in ANY float32 evaluation (torch's included); its gradient
+    mask then differs and the backward pass of that sample is not comparable."""
+    b = copy.deepcopy(blocks).double()
+    b.train(True)
+    xx = x.double()
+    m = torch.full((x.shape[0],), float("inf"), dtype=torch.float64)
+    with torch.no_grad():
+        for blk in b:
+            pre1 = blk.bn1(blk.conv1(xx))
+            pre2 = blk.bn2(blk.conv2(torch.relu(pre1))) + xx
+            m = torch.minimum(m, torch.minimum(pre1.abs().flatten(1).min(1)[0], pre2.abs().flatten(1).min(1)[0]))
+            xx = torch.relu(pre2)
+    return m
+
+
+UNSAFE = 1.5e-6
+
+
+def rel(a, ref):
+    return float((a - ref).abs().max() / max(float(ref.abs().max()), 1e-30))
+
+
+@pytest.mark.parametrize("board,nb,n", [((6, 6), 2, 37), ((3, 3), 1, 70), ((9, 9), 1, 5), ((2, 3), 1, 9), ((6, 6), 3, 256)])
+def test_tower_forward_backward_vs_float64(board, nb, n):
+    H, W = board[0] + 1, board[1] + 1
+    blocks = make_blocks(nb, 7 * nb + n)
+    big = n * H * W * nb > 20000
+    for seed in range(n, n + 40):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.relu(torch.randn(n, 64, H, W, generator=g))      # the tower input is a post-ReLU activation
+        gout = torch.randn(n, 64, H, W, generator=g) * 1e-3        # gradients are small numbers: exercises the dynamic scaling
+        safe = relu_margins(blocks, x) >= UNSAFE
+        if big or bool(safe.all()):
+            break
+    # small cases: inputs without a pre-activation at rounding distance from 0, everything compared tightly; the big case
+    # (millions of ReLU inputs) always has a few: their samples are left out of grad_x and the parameter gradients, which
+    # sum over all samples, are compared loosely
+    assert big or bool(safe.all())
+    loose = not bool(safe.all())
+    o64, gx64, gr64, st64 = run_torch(blocks, x, gout, torch.float64)
+    o32, gx32, gr32, st32 = run_torch(blocks, x, gout, torch.float32)
+    oh, gxh, grh, sth, nbt = run_hip(blocks, x, gout)
+    assert nbt == [1] * (2 * nb)
+
+    def check(name, hip, t32, t64, floor=2e-6):
+        e_hip, e_t32 = rel(hip, t64), rel(t32, t64)
+        assert e_hip <= max(4 * e_t32, floor), (name, e_hip, e_t32)
+
+    check("out", oh, o32, o64)
+    # (a flipped element elsewhere in the batch still reaches the safe samples through the batch statistics: ~1/M)
+    check("grad_x", gxh[safe], gx32[safe], gx64[safe], 5e-5 if loose else 2e-6)
+    for k in gr64:
+        if loose and not (k.endswith("conv1.bias") or k.endswith("conv2.bias")):
+            assert rel(grh[k], gr64[k]) < 2e-2, k
+            continue
+        if k.endswith("conv1.bias") or k.endswith("conv2.bias"):
+            # a conv bias in front of a training-mode BatchNorm has gradient exactly 0; float paths return rounding noise
+            scale = float(gr64[k.replace("bias", "weight")].abs().max())
+            assert float(grh[k].abs().max()) <= 1e-4 * scale + 1e-12, k
+            continue
+        check(k, grh[k], gr32[k], gr64[k])
+    for k in st64:
+        check(k, sth[k], st32[k], st64[k])
+
+
+def test_tower_small_gradients_keep_precision():
+    """Gradients of 1e-12 magnitude (far below f16's range) come back with f32-grade relative precision."""
+    blocks = make_blocks(1, 3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.relu(torch.randn(16, 64, 7, 7, generator=g))
+    gout = torch.randn(16, 64, 7, 7, generator=g) * 1e-12
+    o64, gx64, gr64, _ = run_torch(blocks, x, gout, torch.float64)
+    oh, gxh, grh, _, _ = run_hip(blocks, x, gout)
+    assert rel(gxh, gx64) < 1e-5
+    for k in gr64:
+        if not k.endswith("bias") or "bn" in k:
+            assert rel(grh[k], gr64[k]) < 1e-5, k
+
+
+def test_trainer_errors():
+    from dotsboxesaz_amd import train_tower
+    with pytest.raises(train_tower.TrainerError):
+        train_tower.TowerTrainer(6, 6, 32, 2, 16)          # 64 channels only
+    t = train_tower.TowerTrainer(6, 6, 64, 1, 8)
+    x = torch.zeros(9, 64, 7, 7, device="cuda")
+    w = [torch.zeros(64, 64, 3, 3, device="cuda")] * 2
+    v = [torch.zeros(64, device="cuda")] * 2
+    with pytest.raises(train_tower.TrainerError):
+        t.forward(x, w, v, v, v, v, v)                      # batch beyond max_batch
+    with pytest.raises(train_tower.TrainerError):
+        t.backward(x[:8], v, w, v, v, v)                    # no forward pass held
+    t.close()
