@@ -9,9 +9,9 @@
 // Data layout: activations and gradients live in HBM as f32 NHWC -- row = sample * HW + position, 64 channels = 256 B per
 // row -- which is the row layout of the conv kernels' LDS images.  Per layer l (input A[l], l = 0 .. L-1):
 //   forward    Y[l]   = conv3x3(A[l]) + bias                         k_conv_t   (f16x3 MFMA, as the self-play tower)
-//              mean, invstd over the n*HW rows of Y[l]                k_colsum / k_bn_stats_fin (f64 sums)
+//              mean, invstd over the n*HW rows of Y[l]                k_bn_stats / k_bn_stats_fin (f64 sums)
 //              A[l+1] = relu(bn(Y[l]) (+ A[l-1] for the second conv of a block))   k_bn_apply
-//   backward   g = dA[l+1] * (A[l+1] > 0); sums of g and g*yhat      k_bn_bwd_sums / k_bn_bwd_fin (-> dgamma, dbeta)
+//   backward   g = dA[l+1] * (A[l+1] > 0); sums of g and g*yhat      k_bn_bwd_sums (-> dgamma, dbeta)
 //              dY[l] = gamma*invstd*(g - mean(g) - yhat*mean(g*yhat)) k_bn_bwd_apply (also keeps g for the skip path)
 //              dW[l] = sum_rows A[l](row + tap) x dY[l](row)          k_wgrad (exact f32 MFMA) + k_wgrad_reduce
 //              dA[l] = conv3x3^T(dY[l]) (+ g of the block's end)      k_conv_t with flipped / transposed fragments
@@ -22,6 +22,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <string>
@@ -47,6 +48,7 @@ struct dbaz_trainer {
     float eps = 1e-5f, momentum = 0.1f;
     size_t conv_lds = 0, wgrad_lds = 0;
     bool have_fwd = false;
+    int occ2 = 1; // k_conv_t2 (two workgroups per CU)
     std::string err;
     float *A = nullptr, *Y = nullptr, *G = nullptr, *dA[2] = {nullptr, nullptr}, *dY = nullptr;
     _Float16 *wpk = nullptr;     // [2][L][C*C*9*2] halves: forward and transposed (dgrad) fragments
@@ -193,9 +195,8 @@ struct ConvArgs {
     int n, S, H, W;
 };
 
-struct WPre { f32x4 h0, l0, h1, l1; };
-
-__global__ void __launch_bounds__(TT, 1) k_conv_t(ConvArgs a)
+template <int OCC>
+__device__ __forceinline__ void conv_t_body(const ConvArgs &a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int C = TC, S4 = (C + 8) / 4, KS = C / 32, LO = C / 8, N = 9 * KS, NTT = 4;
@@ -209,11 +210,16 @@ __global__ void __launch_bounds__(TT, 1) k_conv_t(ConvArgs a)
     f32x4 *X4 = reinterpret_cast<f32x4 *>(lds);
     const f32x4 *wpk = reinterpret_cast<const f32x4 *>(a.wpk);
     const int ct0 = (wave & 1) * 2;
-    WPre pre[2];
+    // weight fragments (L2 -> registers) run RD - 1 steps ahead in an RD-deep ring; the first RD - 1 steps are fetched before
+    // the staging so that their latency hides behind it
+    constexpr int RD = OCC == 2 ? 2 : 3;
+    const f32x4 *wb0 = wpk + (size_t)ct0 * N * 2 * 64 + lane;
+    const f32x4 *wb1 = wb0 + (size_t)N * 2 * 64;
+    u128h a_h[2][RD], a_l[2][RD];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const f32x4 *wb = wpk + (size_t)(ct0 + c) * N * 2 * 64 + lane;
-        pre[c].h0 = wb[0]; pre[c].l0 = wb[64]; pre[c].h1 = wb[128]; pre[c].l1 = wb[192];
+    for (int j = 0; j < RD - 1; j++) {
+        a_h[0][j].f = wb0[(size_t)j * 128]; a_l[0][j].f = wb0[(size_t)j * 128 + 64];
+        a_h[1][j].f = wb1[(size_t)j * 128]; a_l[1][j].f = wb1[(size_t)j * 128 + 64];
     }
     const float sx = scale_from_max(*a.in_max);
     {
@@ -259,9 +265,6 @@ __global__ void __launch_bounds__(TT, 1) k_conv_t(ConvArgs a)
     for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int t = 0; t < NTT; t++) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f32x4 *wb0 = wpk + (size_t)ct0 * N * 2 * 64 + lane;
-    const f32x4 *wb1 = wb0 + (size_t)N * 2 * 64;
-    u128h a_h[2][3], a_l[2][3];
     u128h bh[NTT], bl[NTT];
     const char *sb = reinterpret_cast<const char *>(lds);
     int ab[NTT];
@@ -269,20 +272,18 @@ __global__ void __launch_bounds__(TT, 1) k_conv_t(ConvArgs a)
     for (int t = 0; t < NTT; t++)
         ab[t] = ((vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4) * 16;
 #pragma unroll
-    for (int c = 0; c < 2; c++) { a_h[c][0].f = pre[c].h0; a_l[c][0].f = pre[c].l0; a_h[c][1].f = pre[c].h1; a_l[c][1].f = pre[c].l1; }
-#pragma unroll
     for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4);
 #pragma unroll
     for (int t = 0; t < NTT; t++) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + LO * 16);
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        const int cur = i % 3, nxt = (i + 2) % 3;
+        const int cur = i % RD, nxt = (i + RD - 1) % RD;
         const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
-        if (i + 2 < N) {
-            a_h[0][nxt].f = wb0[(size_t)(i + 2) * 128];
-            a_l[0][nxt].f = wb0[(size_t)(i + 2) * 128 + 64];
-            a_h[1][nxt].f = wb1[(size_t)(i + 2) * 128];
-            a_l[1][nxt].f = wb1[(size_t)(i + 2) * 128 + 64];
+        if (i + RD - 1 < N) {
+            a_h[0][nxt].f = wb0[(size_t)(i + RD - 1) * 128];
+            a_l[0][nxt].f = wb0[(size_t)(i + RD - 1) * 128 + 64];
+            a_h[1][nxt].f = wb1[(size_t)(i + RD - 1) * 128];
+            a_l[1][nxt].f = wb1[(size_t)(i + RD - 1) * 128 + 64];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -332,8 +333,16 @@ __global__ void __launch_bounds__(TT, 1) k_conv_t(ConvArgs a)
     }
 }
 
+// two instantiations: 1 workgroup per CU (144 registers) or 2 (128 registers, a few spills): the second overlaps one
+// workgroup's staging and stores with the other's MFMA loop
+__global__ void __launch_bounds__(TT, 2) k_conv_t(ConvArgs a) { conv_t_body<1>(a); }
+__global__ void __launch_bounds__(TT, 4) k_conv_t2(ConvArgs a) { conv_t_body<2>(a); }
+
 // ------------------------------------------------------------------------------------
-// column sums over the rows of [M][C] tensors, f64: the workgroup's 512 threads = 32 row lanes x 16 channel quads
+// column sums over the rows of [M][C] tensors, f64: the workgroup's 512 threads = 32 row lanes x 16 channel quads write one
+// partial per workgroup; a one-workgroup kernel (colsum_total) adds the partials up.  (Letting the last workgroup to arrive
+// do that -- __threadfence + a device-scope counter -- made these kernels 4-6x slower: every fence writes the XCD's dirty L2
+// lines back, and these kernels have just written 50 MB.)
 // ------------------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ void block_colsum_store(double (&s)[K][4], double *part /*[blocks][K][C]*/)
@@ -353,8 +362,48 @@ __device__ __forceinline__ void block_colsum_store(double (&s)[K][4], double *pa
     }
 }
 
-// partials of sum(y) and sum(y^2)
-__global__ void __launch_bounds__(TT) k_colsum_y(const f32x4 *__restrict__ y4, long long M, double *part)
+// one workgroup of 512 threads (8 partial lanes x 64 channels): tot[k][c] = sum of the partials
+template <int K>
+__device__ __forceinline__ void colsum_total(const double *part, int nparts, double (*tot)[TC] /* LDS [K][C] */)
+{
+    __shared__ double red[TT / 64][K][TC];
+    const int tid = threadIdx.x, c = tid & 63, j = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double v0 = 0.0, v1 = 0.0;
+        int bb = j;
+        for (; bb + TT / 64 < nparts; bb += 2 * (TT / 64)) {
+            v0 += part[((size_t)bb * K + k) * TC + c];
+            v1 += part[((size_t)(bb + TT / 64) * K + k) * TC + c];
+        }
+        if (bb < nparts) v0 += part[((size_t)bb * K + k) * TC + c];
+        red[j][k][c] = v0 + v1;
+    }
+    __syncthreads();
+    if (tid < K * TC) {
+        const int k = tid / TC, cc = tid - k * TC;
+        double v = 0.0;
+        for (int jj = 0; jj < TT / 64; jj++) v += red[jj][k][cc];
+        tot[k][cc] = v;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void block_atomic_max(float mx, unsigned *amax)
+{
+    __shared__ float s_mx[TT / 64];
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.0f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) m = fmaxf(m, s_mx[i]);
+        if (m > 0.0f) atomicMax(amax, __float_as_uint(m));
+    }
+}
+
+// partials of sum(y), sum(y^2) over the rows
+__global__ void __launch_bounds__(TT) k_bn_stats(const f32x4 *__restrict__ y4, long long M, double *part)
 {
     double s[2][4] = {};
     const int cq = threadIdx.x & 15;
@@ -366,22 +415,24 @@ __global__ void __launch_bounds__(TT) k_colsum_y(const f32x4 *__restrict__ y4, l
     block_colsum_store<2>(s, part);
 }
 
-// final sums -> batch mean / invstd, running statistics (BatchNorm2d training mode: momentum 0.1, unbiased running variance)
-__global__ void __launch_bounds__(TC) k_bn_stats_fin(const double *part, int nparts, long long M, float eps, float momentum,
-                                                     float *mean, float *invstd, float *run_mean, float *run_var)
+// -> batch mean / invstd and the running statistics (BatchNorm2d training mode: momentum 0.1, unbiased running variance)
+__global__ void __launch_bounds__(TT) k_bn_stats_fin(const double *part, int nparts, long long M, float eps, float momentum, float *mean,
+                                                     float *invstd, float *run_mean, float *run_var)
 {
-    const int c = threadIdx.x;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nparts; b++) { s += part[((size_t)b * 2 + 0) * TC + c]; q += part[((size_t)b * 2 + 1) * TC + c]; }
-    const double m = s / (double)M;
-    double var = q / (double)M - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (run_mean) run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + (double)momentum * m);
-    if (run_var) {
-        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
-        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + (double)momentum * unb);
+    __shared__ double tot[2][TC];
+    colsum_total<2>(part, nparts, tot);
+    if (threadIdx.x < TC) {
+        const int c = threadIdx.x;
+        const double m = tot[0][c] / (double)M;
+        double var = tot[1][c] / (double)M - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + (double)momentum * m);
+        if (run_var) {
+            const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + (double)momentum * unb);
+        }
     }
 }
 
@@ -402,11 +453,11 @@ __global__ void __launch_bounds__(256) k_bn_apply(const f32x4 *__restrict__ y4, 
         for (int e = 0; e < 4; e++) { v[e] = fmaxf(v[e], 0.0f); mx = fmaxf(mx, v[e]); }
         out4[i] = v;
     }
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(amax, __float_as_uint(mx));
+    block_atomic_max(mx, amax); // one atomic per workgroup (one per wave of a 4 096-workgroup grid serialised for 160 us)
 }
 
-// backward, pass 1: g = dA * (A_out > 0); partials of sum(g) and sum(g * yhat)
+// backward, pass 1: g = dA * (A_out > 0); partials of sum(g) and sum(g * yhat); the _fin kernel turns them into dbeta, dgamma
+// and `sums` for pass 2 and clears the max|dY| word pass 2 accumulates into
 __global__ void __launch_bounds__(TT) k_bn_bwd_sums(const f32x4 *__restrict__ dA4, const f32x4 *__restrict__ aout4, const f32x4 *__restrict__ y4,
                                                     long long M, const float *mean, const float *invstd, double *part)
 {
@@ -427,23 +478,22 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_sums(const f32x4 *__restrict__ dA
     block_colsum_store<2>(s, part);
 }
 
-// final sums of K quantities; out_a / out_b (optional) receive sums 0 / 1 as f32 (dbeta, dgamma); zero = word to clear
-template <int K>
-__global__ void __launch_bounds__(TC) k_sums_fin(const double *part, int nparts, double *sums, float *out0, float *out1, unsigned *zero)
+__global__ void __launch_bounds__(TT) k_bn_bwd_sums_fin(const double *part, int nparts, double *sums, float *dbeta, float *dgamma, unsigned *zero)
 {
-    const int c = threadIdx.x;
-    for (int k = 0; k < K; k++) {
-        double s = 0.0;
-        for (int b = 0; b < nparts; b++) s += part[((size_t)b * K + k) * TC + c];
-        if (sums) sums[k * TC + c] = s;
-        if (k == 0 && out0) out0[c] = (float)s;
-        if (k == 1 && out1) out1[c] = (float)s;
+    __shared__ double tot[2][TC];
+    colsum_total<2>(part, nparts, tot);
+    if (threadIdx.x < TC) {
+        const int c = threadIdx.x;
+        sums[c] = tot[0][c];
+        sums[TC + c] = tot[1][c];
+        dbeta[c] = (float)tot[0][c];
+        dgamma[c] = (float)tot[1][c];
     }
-    if (zero && c == 0) *zero = 0u;
+    if (threadIdx.x == 0) *zero = 0u;
 }
 
 // backward, pass 2: dY = gamma * invstd * (g - sum(g)/M - yhat * sum(g*yhat)/M); keeps g (skip path of a block's end);
-// tracks max|dY|; partials of sum(dY) (the conv bias gradient)
+// tracks max|dY|; partials of sum(dY) (the conv bias gradient: k_dbias_fin)
 __global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ dA4, const f32x4 *__restrict__ aout4, const f32x4 *__restrict__ y4,
                                                      long long M, const float *mean, const float *invstd, const float *gamma,
                                                      const double *sums, f32x4 *__restrict__ dY4, f32x4 *__restrict__ g4,
@@ -475,78 +525,141 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ d
         dY4[r * 16 + cq] = o;
         if (g4) g4[r * 16 + cq] = g;
     }
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(amax, __float_as_uint(mx));
+    block_atomic_max(mx, amax);
     block_colsum_store<1>(s, part);
+}
+
+__global__ void __launch_bounds__(TT) k_dbias_fin(const double *part, int nparts, float *dbias)
+{
+    __shared__ double tot[1][TC];
+    colsum_total<1>(part, nparts, tot);
+    if (threadIdx.x < TC) dbias[threadIdx.x] = (float)tot[0][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------
 // weight gradient dW[tap][cin][cout] = sum over rows of A(row + tap offset)[cin] * dY(row)[cout], exact f32 on
-// v_mfma_f32_16x16x4_f32 (m = cin, n = cout, k = 4 consecutive rows).  A workgroup stages chunks of Sw samples (both
-// tensors, f32 rows of C+16 dwords: the two rows of a 32-lane read group fall on disjoint banks) and keeps the whole
-// 9 x 64 x 64 gradient in registers: wave w owns cin tile w & 3 and cout tiles 2 (w >> 2), +1 for all 9 taps (18
-// accumulator tiles); the workgroups' partial gradients are summed by k_wgrad_reduce.
+// v_mfma_f32_16x16x4_f32 (m = cin, n = cout, k = 4 consecutive rows).  A workgroup stages chunks of Sw samples: dY as plain
+// rows, A into a ZERO-PADDED image (one pad column per line, one pad line per sample, guard rows in front), so that a tap is a
+// constant row offset and needs no border mask; tab[row] holds the byte offset of a dY row's window in that image.  Rows are
+// C+16 dwords (the two rows of a 32-lane read group fall on disjoint banks).  The whole 9 x 64 x 64 gradient stays in
+// registers: wave w owns cin tile w & 3 and cout tiles 2 (w >> 2), +1 for all 9 taps (18 accumulator tiles); the operands
+// of K-step k+1 are read from LDS while the 18 MFMAs of step k issue, and the next chunk's rows travel HBM -> registers
+// under the whole loop.  The workgroups' partial gradients are summed by k_wgrad_reduce.
 // ------------------------------------------------------------------------------------
 #define WG_STRIDE (TC + 16)
+#define WG_MAXLD 13 // float4 per thread and chunk: 2 images x <= 208 rows x 16 quads / 512 threads
 
-__global__ void __launch_bounds__(TT, 1) k_wgrad(const float *__restrict__ act, const float *__restrict__ dy, int n, int Sw, int H, int W,
+struct WgGeo { int RW, RA, PW, G; };
+__host__ __device__ inline WgGeo wg_geo(int Sw, int H, int W)
+{
+    WgGeo g;
+    g.PW = W + 1;
+    g.G = g.PW + 1;
+    g.RW = (Sw * H * W + 3) & ~3;                 // dY rows per chunk, padded to the K step
+    g.RA = 2 * g.G + Sw * (H + 1) * g.PW;          // rows of the padded A image
+    return g;
+}
+static size_t wg_lds_bytes(int Sw, int H, int W)
+{
+    const WgGeo g = wg_geo(Sw, H, W);
+    return (size_t)(g.RA + g.RW) * WG_STRIDE * 4 + (size_t)g.RW * 4;
+}
+
+__global__ void __launch_bounds__(TT, 2) k_wgrad(const float *__restrict__ act, const float *__restrict__ dy, int n, int Sw, int H, int W,
                                                  float *__restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int HW = H * W;
-    const int RW = (Sw * HW + 3) & ~3; // rows per chunk, padded to the K step
+    const WgGeo geo = wg_geo(Sw, H, W);
+    const int RW = geo.RW, PW = geo.PW;
     float *Ai = lds;
-    float *Di = lds + (size_t)RW * WG_STRIDE;
-    unsigned short *mask = reinterpret_cast<unsigned short *>(Di + (size_t)RW * WG_STRIDE);
+    float *Di = lds + (size_t)geo.RA * WG_STRIDE;
+    int *tab = reinterpret_cast<int *>(Di + (size_t)RW * WG_STRIDE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cit = wave & 3, ch = wave >> 2;
     const int m16 = lane & 15, gq = lane >> 4;
     f32x4 acc[9][2];
 #pragma unroll
     for (int t = 0; t < 9; t++) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int i = tid; i < geo.RA * (WG_STRIDE / 4); i += TT) reinterpret_cast<f32x4 *>(Ai)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int r = tid; r < RW; r += TT) {
-        const int pos = r % HW, y = pos / W, x = pos - y * W;
-        int m = 0;
-        for (int tap = 0; tap < 9; tap++) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
+        int v = 0;
+        if (r < Sw * HW) {
+            const int sidx = r / HW, pos = r - sidx * HW, y = pos / W, x = pos - y * W;
+            v = (geo.G + sidx * (H + 1) * PW + y * PW + x - PW - 1) * WG_STRIDE * 4; // window start: tap (0,0) = row - PW - 1
         }
-        mask[r] = (unsigned short)m;
+        tab[r] = v;
     }
     const int nchunks = (n + Sw - 1) / Sw;
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const int s0 = chunk * Sw, ns = min(Sw, n - s0), R = ns * HW;
-        __syncthreads(); // the previous chunk's reads are done
-        {
-            const f32x4 *a4 = reinterpret_cast<const f32x4 *>(act) + (size_t)s0 * HW * 16;
-            const f32x4 *d4 = reinterpret_cast<const f32x4 *>(dy) + (size_t)s0 * HW * 16;
-            for (int i = tid; i < RW * 16; i += TT) {
-                const int row = i >> 4, c4 = i & 15;
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4 *>(Ai + (size_t)row * WG_STRIDE + c4 * 4) = row < R ? a4[i] : z;
-                *reinterpret_cast<f32x4 *>(Di + (size_t)row * WG_STRIDE + c4 * 4) = row < R ? d4[i] : z;
+    f32x4 pf[WG_MAXLD];
+    const int img4 = RW * 16; // float4 per image
+    auto issue = [&](int chunk) {
+        const int s0 = chunk * Sw, R = min(Sw, n - s0) * HW;
+        const f32x4 *a4 = reinterpret_cast<const f32x4 *>(act) + (size_t)s0 * HW * 16;
+        const f32x4 *d4 = reinterpret_cast<const f32x4 *>(dy) + (size_t)s0 * HW * 16;
+#pragma unroll
+        for (int j = 0; j < WG_MAXLD; j++) {
+            const int i = tid + j * TT;
+            const int which = i >= img4, ii = i - which * img4;
+            pf[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (i < 2 * img4 && (ii >> 4) < R) pf[j] = which ? d4[ii] : a4[ii];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < WG_MAXLD; j++) {
+            const int i = tid + j * TT;
+            const int which = i >= img4, ii = i - which * img4;
+            if (i < 2 * img4) {
+                const int row = ii >> 4, c4 = ii & 15;
+                if (which) *reinterpret_cast<f32x4 *>(Di + (size_t)row * WG_STRIDE + c4 * 4) = pf[j];
+                else if (row < Sw * HW) // (rows of samples past the batch's end arrive as zeros; their dY rows are zero as well)
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(Ai) + tab[row] + (PW + 1) * WG_STRIDE * 4 + c4 * 16) = pf[j];
             }
         }
+    };
+    __syncthreads(); // tab, zeroed image
+    if ((int)blockIdx.x < nchunks) issue(blockIdx.x);
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) toff[t] = ((t / 3) * PW + (t % 3)) * WG_STRIDE * 4;
+    const char *abase = reinterpret_cast<const char *>(Ai) + (cit * 16 + m16) * 4;
+    const float *dbase = Di + ch * 32 + m16;
+    const int NK = RW / 4;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        __syncthreads(); // the previous chunk's reads are done
+        commit();
         __syncthreads();
-        const float *ab = Ai + cit * 16 + m16;
-        const float *db = Di + ch * 32 + m16;
-#pragma unroll 2
-        for (int k0 = 0; k0 < RW; k0 += 4) {
-            const int r = k0 + gq;
-            const int m = mask[r];
-            const float b0 = db[(size_t)r * WG_STRIDE], b1 = db[(size_t)r * WG_STRIDE + 16];
-            float av[9];
+        if (chunk + (int)gridDim.x < nchunks) issue(chunk + gridDim.x);
+        float a0[9], a1[9], b0[2], b1[2];
+        auto load = [&](float (&av)[9], float (&bv)[2], int k, int tb) {
+            const int r = 4 * k + gq;
+            bv[0] = dbase[(size_t)r * WG_STRIDE];
+            bv[1] = dbase[(size_t)r * WG_STRIDE + 16];
 #pragma unroll
-            for (int tap = 0; tap < 9; tap++) {
-                const int rr = min(max(r + (tap / 3 - 1) * W + (tap % 3 - 1), 0), RW - 1);
-                const float v = ab[(size_t)rr * WG_STRIDE];
-                av[tap] = ((m >> tap) & 1) ? v : 0.0f;
-            }
+            for (int t = 0; t < 9; t++) av[t] = *reinterpret_cast<const float *>(abase + tb + toff[t]);
+        };
+        auto mma = [&](const float (&av)[9], const float (&bv)[2]) {
 #pragma unroll
-            for (int tap = 0; tap < 9; tap++) {
-                acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], b0, acc[tap][0], 0, 0, 0);
-                acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], b1, acc[tap][1], 0, 0, 0);
+            for (int t = 0; t < 9; t++) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[0], acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[1], acc[t][1], 0, 0, 0);
             }
+        };
+        int tbA = tab[gq], tbB = tab[min(4 + gq, RW - 1)], tbC = 0, tbD = 0;
+        load(a0, b0, 0, tbA);
+        for (int k = 0; k < NK; k += 2) {
+            tbC = tab[min(4 * (k + 2) + gq, RW - 1)];
+            tbD = tab[min(4 * (k + 3) + gq, RW - 1)];
+            if (k + 1 < NK) load(a1, b1, k + 1, tbB);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 2 < NK) load(a0, b0, k + 2, tbC);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < NK) mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            tbB = tbD;
         }
     }
     // lane holds dW[tap][cin = cit*16 + 4 gq + i][cout = (2 ch + j)*16 + m16]
@@ -560,15 +673,28 @@ __global__ void __launch_bounds__(TT, 1) k_wgrad(const float *__restrict__ act, 
                 o[((size_t)tap * TC + cit * 16 + 4 * gq + i) * TC + (2 * ch + j) * 16 + m16] = acc[tap][j][i];
 }
 
-// sums the workgroups' partial gradients (f64) and writes torch's [cout][cin][3][3]
+// sums the workgroups' partial gradients (f64) and writes torch's [cout][cin][3][3]: 64 outputs x 4 partial lanes per block
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ part, int nparts, float *__restrict__ dw)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x; // (tap * C + cin) * C + cout
-    if (i >= 9 * TC * TC) return;
-    double s = 0.0;
-    for (int b = 0; b < nparts; b++) s += (double)part[(size_t)b * 9 * TC * TC + i];
-    const int co = i & 63, ci = (i >> 6) & 63, tap = i >> 12;
-    dw[((size_t)co * TC + ci) * 9 + tap] = (float)s;
+    __shared__ double red[4][64];
+    const int o = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o; // (tap * C + cin) * C + cout
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = j;
+    for (; b + 12 < nparts; b += 16) {
+        s0 += (double)part[(size_t)b * 9 * TC * TC + i];
+        s1 += (double)part[(size_t)(b + 4) * 9 * TC * TC + i];
+        s2 += (double)part[(size_t)(b + 8) * 9 * TC * TC + i];
+        s3 += (double)part[(size_t)(b + 12) * 9 * TC * TC + i];
+    }
+    for (; b < nparts; b += 4) s0 += (double)part[(size_t)b * 9 * TC * TC + i];
+    red[j][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (j == 0) {
+        const double s = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+        const int co = i & 63, ci = (i >> 6) & 63, tap = i >> 12;
+        dw[((size_t)co * TC + ci) * 9 + tap] = (float)s;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -605,13 +731,13 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) t->cus = prop.multiProcessorCount;
     t->S = 256 / t->HW;
-    t->Sw = 196 / t->HW;
+    t->Sw = 1; // samples per k_wgrad chunk: as many as the prefetch registers (208 rows) and 150 KB of LDS hold
+    while ((t->Sw + 1) * t->HW <= 208 && wg_lds_bytes(t->Sw + 1, t->H, t->W) <= 150 * 1024) t->Sw++;
     {
         const int S4 = (TC + 8) / 4;
         const int zu = (t->S * t->HW * S4 + 15) & ~15;
         t->conv_lds = (size_t)(zu + 3 * S4) * 16;
-        const int RW = (t->Sw * t->HW + 3) & ~3;
-        t->wgrad_lds = (size_t)RW * WG_STRIDE * 4 * 2 + (size_t)((RW + 7) & ~7) * 2;
+        t->wgrad_lds = wg_lds_bytes(t->Sw, t->H, t->W);
     }
     const size_t ae = act_elems(t);
     hipError_t e = hipSuccess;
@@ -631,6 +757,8 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     alloc((void **)&t->sums, (size_t)4 * TC * 8);
     alloc((void **)&t->wg_part, (size_t)t->cus * 9 * TC * TC * 4);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
+    t->occ2 = getenv("DBAZ_TRAIN_OCC1") ? 0 : 1;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_lds);
     if (e != hipSuccess) {
         const std::string msg = hipGetErrorString(e);
@@ -667,16 +795,17 @@ extern "C" int dbaz_trainer_forward(dbaz_trainer *t, int32_t n, const float *x, 
     const int grid = (n + t->S - 1) / t->S;
     const int rb = red_blocks(M);
     const long long n4 = M * 16;
-    const int ab = (int)std::min<long long>((n4 + 255) / 256, 4096);
+    const int ab = (int)std::min<long long>((n4 + 255) / 256, 1024);
     for (int l = 0; l < L; l++) {
         ConvArgs ca;
         ca.in = t->A + ae * l; ca.in_max = t->amax + l;
         ca.wpk = t->wpk + (size_t)l * TC * TC * 9 * 2; ca.wsc = t->wsc + l;
         ca.bias = conv_b[l]; ca.add = nullptr; ca.out = t->Y + ae * l;
         ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
-        hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
-        hipLaunchKernelGGL(k_colsum_y, dim3(rb), dim3(TT), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l), M, t->part);
-        hipLaunchKernelGGL(k_bn_stats_fin, dim3(1), dim3(TC), 0, s, t->part, rb, M, t->eps, t->momentum, t->mean + l * TC,
+        if (t->occ2) hipLaunchKernelGGL(k_conv_t2, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        else hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        hipLaunchKernelGGL(k_bn_stats, dim3(rb), dim3(TT), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l), M, t->part);
+        hipLaunchKernelGGL(k_bn_stats_fin, dim3(1), dim3(TT), 0, s, t->part, rb, M, t->eps, t->momentum, t->mean + l * TC,
                            t->invstd + l * TC, run_mean ? run_mean[l] : nullptr, run_var ? run_var[l] : nullptr);
         hipLaunchKernelGGL(k_bn_apply, dim3(ab), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l),
                            (l & 1) ? reinterpret_cast<const f32x4 *>(t->A + ae * (l - 1)) : nullptr,
@@ -717,21 +846,21 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
         const f32x4 *ao4 = reinterpret_cast<const f32x4 *>(t->A + ae * (l + 1));
         const f32x4 *y4 = reinterpret_cast<const f32x4 *>(t->Y + ae * l);
         hipLaunchKernelGGL(k_bn_bwd_sums, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, t->part);
-        hipLaunchKernelGGL((k_sums_fin<2>), dim3(1), dim3(TC), 0, s, t->part, rb, t->sums, g_bn_b[l], g_bn_w[l], dymax);
+        hipLaunchKernelGGL(k_bn_bwd_sums_fin, dim3(1), dim3(TT), 0, s, t->part, rb, t->sums, g_bn_b[l], g_bn_w[l], dymax);
         hipLaunchKernelGGL(k_bn_bwd_apply, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, bn_w[l],
                            t->sums, reinterpret_cast<f32x4 *>(t->dY), (l & 1) ? reinterpret_cast<f32x4 *>(t->G) : (f32x4 *)nullptr,
                            dymax, t->part);
-        hipLaunchKernelGGL((k_sums_fin<1>), dim3(1), dim3(TC), 0, s, t->part, rb, (double *)nullptr, g_conv_b[l], (float *)nullptr,
-                           (unsigned *)nullptr);
+        hipLaunchKernelGGL(k_dbias_fin, dim3(1), dim3(TT), 0, s, t->part, rb, g_conv_b[l]);
         hipLaunchKernelGGL(k_wgrad, dim3(wg), dim3(TT), t->wgrad_lds, s, t->A + ae * l, t->dY, n, t->Sw, t->H, t->W, t->wg_part);
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((9 * TC * TC + 255) / 256), dim3(256), 0, s, t->wg_part, wg, g_conv_w[l]);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(9 * TC * TC / 64), dim3(256), 0, s, t->wg_part, wg, g_conv_w[l]);
         ConvArgs ca;
         ca.in = t->dY; ca.in_max = dymax;
         ca.wpk = t->wpk + ((size_t)L + l) * TC * TC * 9 * 2; ca.wsc = t->wsc + L + l;
         ca.bias = nullptr; ca.out = t->dA[1 - cur];
         ca.add = (l & 1) ? nullptr : t->G; // the input of a block's first conv is also the block's skip input: + g of its end
         ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
-        hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        if (t->occ2) hipLaunchKernelGGL(k_conv_t2, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        else hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         cur = 1 - cur;
     }
     hipLaunchKernelGGL(k_rows_to_nchw, dim3(n), dim3(256), (size_t)HW * (TC + 1) * 4, s, t->dA[cur], grad_x, HW);

@@ -3,9 +3,11 @@
 (nn.py:292-313) and `GenerationLrScheduler` (nn.py:276-289).
 
 What runs where: the DATA side (dataset build from replay rows in HBM, batch gather, symmetries) is
-hand-written HIP (`train_data.py` -> csrc/replay.hip).  The forward/backward/optimizer arithmetic of
-this file is torch on ROCm (MIOpen/rocBLAS autograd) -- plumbing around the product, not a kernel of
-this repository, and never on the self-play path: the weight containers of `nn.py` still refuse
+hand-written HIP (`train_data.py` -> csrc/replay.hip).  The residual blocks of a 64-channel ResNetZero
+-- 98 % of the step's FLOPs -- run forward and backward in hand-written HIP as well when the model is in
+training mode on the GPU (`train_tower.py` -> csrc/train.hip; `hip_tower=False` keeps them on torch).
+The rest of this file's arithmetic (bn_input, conv0, the heads, the loss, SGD) is torch on ROCm --
+plumbing around the product, never on the self-play path: the weight containers of `nn.py` still refuse
 `forward()`; `training_forward` composes their sub-modules explicitly for autograd.
 """
 import os
@@ -21,9 +23,11 @@ def _get(d, k, default=None):
     return getattr(d, k, default)
 
 
-def training_forward(model, x):
+def training_forward(model, x, hip_tower=None):
     """(log_softmax policy, tanh value) of a `nn.ResNetZero` / `nn.SimpleNN` container, in the
-    reference's operation order (nn.py:23-28,48-57,81-86,98-104,117-122; dots_boxes_nn.py:85-98)."""
+    reference's operation order (nn.py:23-28,48-57,81-86,98-104,117-122; dots_boxes_nn.py:85-98).
+    hip_tower: None = the HIP residual tower whenever it applies (training mode, CUDA tensor, 64 channels),
+    False = torch's, True = required."""
     if getattr(model, "kind", None) == "simplenn":
         for i in range(5):
             x = getattr(model, "bn%d" % i)(F.relu(getattr(model, "conv%d" % i)(x)))
@@ -34,11 +38,20 @@ def training_forward(model, x):
     x = model.bn_input(x)
     r = model.resnet
     x = F.relu(r.bn0(r.conv0(x)))
-    for blk in r.resblocks:
-        y = F.relu(blk.bn1(blk.conv1(x)))
-        y = blk.bn2(blk.conv2(y))
-        y += x
-        x = F.relu(y)
+    use_hip = False
+    if hip_tower is not False and model.training and x.is_cuda:
+        from . import train_tower
+        use_hip = train_tower.supported(model, x)
+    if hip_tower is True and not use_hip:
+        raise RuntimeError("the HIP training tower needs a 64-channel ResNetZero in training mode on a CUDA tensor")
+    if use_hip:
+        x = train_tower.resblocks_forward(model, x)
+    else:
+        for blk in r.resblocks:
+            y = F.relu(blk.bn1(blk.conv1(x)))
+            y = blk.bn2(blk.conv2(y))
+            y += x
+            x = F.relu(y)
     ph, vh = model.policy_head, model.value_head
     p = F.relu(ph.bn0(ph.conv0(x)))
     p = F.log_softmax(ph.fc(p.view(p.size(0), -1)), dim=1)

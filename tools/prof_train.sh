@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of the training step (tools/train_step_time.py); run on the GPU box from the repo root:
+#   bash tools/prof_train.sh <tag> [train_step_time.py arguments]
+tag=$1; shift
+out=$PWD/gpurun_out/prof_train_$tag
+mkdir -p $out
+repo=$PWD
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python3 $repo/tools/train_step_time.py "$@" > $out/step.json 2> $out/err.txt
+cd $repo
+python3 - <<PY
+import csv
+rows = list(csv.DictReader(open("$out/p_kernel_stats.csv")))
+for r in rows[:22]:
+    print("%-60s calls %5s avg %9.1f us total %8.1f ms" % (r["Name"].split("(")[0][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+PY
+cat $out/step.json

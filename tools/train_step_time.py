@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Times the optimizer step of the generation loop (torch on ROCm; plumbing, not a kernel of this repo)
-fed by the HIP batch kernel: 6x6, ResNetZero 20x64, batch 4096, SGD momentum.  Prints one JSON line."""
+"""Times the optimizer step of the generation loop fed by the HIP batch kernel: 6x6, ResNetZero 20x64, batch 4096, SGD
+momentum.  Residual tower forward/backward on csrc/train.hip (default) or on torch/MIOpen (--torch); heads, loss and
+SGD are torch either way.  Prints one JSON line.
+
+    python tools/train_step_time.py [batch] [--torch] [--steps K]"""
 import json
 import os
 import sys
@@ -16,7 +19,10 @@ from dotsboxesaz_amd.engine import Engine  # noqa: E402
 from dotsboxesaz_amd.self_play import _DevBuf  # noqa: E402
 from dotsboxesaz_amd.train_data import ReplayStore, SymmetriesGenerator  # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(_pos[0]) if _pos else 4096
+HIP = "--torch" not in sys.argv
+K = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 10
 e = Engine(6, 6, 256, mcts_num_read=12, noise=(0.8, 0.25), evaluator="uniform", seed=1)
 e.selfplay_start(512, 0)
 e.run()
@@ -45,7 +51,7 @@ def epoch(steps):
             except StopIteration:
                 break
             t_data += time.perf_counter() - t0
-            p, v = T.training_forward(model, boards)
+            p, v = T.training_forward(model, boards, hip_tower=HIP)
             loss, _ = crit(p, v, pi, z)
             loss.backward()
             opt.step()
@@ -57,9 +63,8 @@ def epoch(steps):
 
 epoch(3)
 t0 = time.perf_counter()
-K = 10
 td = epoch(K)
 dt = time.perf_counter() - t0
-print(json.dumps({"what": "training step, torch-ROCm forward/backward/SGD fed by k_make_batch", "board": "6x6", "net": "ResNetZero 20x64",
+print(json.dumps({"what": "training step fed by k_make_batch; residual tower on %s, heads/loss/SGD on torch" % ("csrc/train.hip" if HIP else "torch (MIOpen)"), "board": "6x6", "net": "ResNetZero 20x64",
                   "batch": B, "dataset_rows": len(ds), "ms_per_step": 1e3 * dt / K, "ms_data_per_step": 1e3 * td / K,
                   "samples_per_sec": B * K / dt}))
