@@ -49,6 +49,8 @@ struct dbaz_trainer {
     size_t conv_lds = 0, wgrad_lds = 0;
     bool have_fwd = false;
     int occ2 = 1; // k_conv_t2 (two workgroups per CU)
+    int wgrad_h3 = 1, Swh = 1; // k_wgrad_h3 (f16x3) and its samples per chunk; 0: the exact-f32 k_wgrad
+    size_t wgrad_h3_lds = 0;
     std::string err;
     float *A = nullptr, *Y = nullptr, *G = nullptr, *dA[2] = {nullptr, nullptr}, *dY = nullptr;
     _Float16 *wpk = nullptr;     // [2][L][C*C*9*2] halves: forward and transposed (dgrad) fragments
@@ -673,6 +675,179 @@ __global__ void __launch_bounds__(TT, 2) k_wgrad(const float *__restrict__ act, 
                 o[((size_t)tap * TC + cit * 16 + 4 * gq + i) * TC + (2 * ch + j) * 16 + m16] = acc[tap][j][i];
 }
 
+// ------------------------------------------------------------------------------------
+// The same weight gradient on the f16 MFMA pipe (f16x3, as k_conv_t): K = 32 rows per v_mfma_f32_16x16x32_f16 step, both
+// operands (hi, lo) pairs of halves scaled by the tensors' own maxima.  The MFMA wants 8 consecutive K values (rows) of one
+// channel per lane while the images are row-major [row][channel]: gfx950's transposing LDS read (ds_read_b64_tr_b16) hands
+// every lane column i of four rows whose addresses the lanes supply, so rows need not even be contiguous -- K slot 4h + q of
+// lane group g is row 16h + 4g + q of the step for BOTH operands (any bijection is a valid K order).
+// Images: rows of [64 hi | 64 lo | 16 pad] halves (288 B: eight consecutive rows cover the 64 banks once).  dY is stored with
+// one zero pad column per line (K runs over H x (W+1) cells per sample: a K step is whole lines), A zero-padded as in
+// k_wgrad; tabA[row] = byte offset of a dY row's 3x3 window in the A image.  Wave w owns cin tile w & 3 and cout tiles
+// 2 (w >> 2), +1 for all 9 taps; A fragments run two taps ahead in a 3-deep ring.
+// ------------------------------------------------------------------------------------
+#define WH_SB 288 // bytes per image row
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+union FragH { s4v s[2]; f16x8 h; };
+
+struct WhGeo { int RK, RA, PW, G, NK; };
+__host__ __device__ inline WhGeo wh_geo(int Sw, int H, int W)
+{
+    WhGeo g;
+    g.PW = W + 1;
+    g.G = g.PW + 1;
+    g.NK = (Sw * H * g.PW + 31) / 32;              // K steps per chunk
+    g.RK = g.NK * 32;                              // rows of the dY image
+    g.RA = 2 * g.G + Sw * (H + 1) * g.PW;          // rows of the padded A image (the last window ends at row Sw*(H+1)*PW + G)
+    return g;
+}
+static size_t wh_lds_bytes(int Sw, int H, int W)
+{
+    const WhGeo g = wh_geo(Sw, H, W);
+    return (size_t)(g.RA + g.RK) * WH_SB + (size_t)g.RK * 4 + (size_t)Sw * H * W * 4;
+}
+
+typedef s4v __attribute__((address_space(3))) *lds_s4v_ptr;
+// transposing read at a 32-bit LDS byte address
+__device__ __forceinline__ s4v tr_read(unsigned a) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(size_t)a); }
+
+template <int PWC> // W + 1 at compile time (tap offsets become immediates of the reads), 0 = any board
+__global__ void __launch_bounds__(TT, 2) k_wgrad_h3(const float *__restrict__ act, const float *__restrict__ dy, const unsigned *act_max,
+                                                    const unsigned *dy_max, int n, int Sw, int H, int W, float *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int HW = H * W;
+    const WhGeo geo = wh_geo(Sw, H, W);
+    const int PW = PWC ? PWC : geo.PW, NK = geo.NK;
+    char *Ai = reinterpret_cast<char *>(lds);
+    char *Di = Ai + (size_t)geo.RA * WH_SB;
+    int *tabA = reinterpret_cast<int *>(Di + (size_t)geo.RK * WH_SB);   // [RK] window start of dY row j in the A image (bytes)
+    int *rowmap = tabA + geo.RK;                                        // [Sw*HW] dY row | A row << 16 of a real position
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cit = wave & 3, ch = wave >> 2;
+    const int m16 = lane & 15, gq = lane >> 4;
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; t++) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int i = tid; i < (geo.RA + geo.RK) * (WH_SB / 16); i += TT) reinterpret_cast<f32x4 *>(Ai)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int per_s = H * PW; // dY rows per sample
+    for (int j = tid; j < geo.RK; j += TT) tabA[j] = j < Sw * per_s ? (j + (j / per_s) * PW) * WH_SB : 0;
+    for (int r = tid; r < Sw * HW; r += TT) {
+        const int sidx = r / HW, pos = r - sidx * HW, y = pos / W, x = pos - y * W;
+        const int j = sidx * per_s + y * PW + x;
+        rowmap[r] = j | ((geo.G + sidx * (H + 1) * PW + y * PW + x) << 16);
+    }
+    const float sA = scale_from_max(*act_max), sD = scale_from_max(*dy_max);
+    const int nchunks = (n + Sw - 1) / Sw;
+    f32x4 pf[WG_MAXLD];
+    const int img4 = Sw * HW * 16; // float4 per tensor and chunk
+    // (tz: an opaque zero -- without it the compiler keeps the 13 global offsets and 13 LDS destinations of the staging, which
+    // do not depend on the chunk, in 39 registers across the MFMA loop and parks the prefetched rows in scratch instead)
+    auto issue = [&](int chunk, int tz) {
+        const int s0 = chunk * Sw, R = min(Sw, n - s0) * HW;
+        const f32x4 *a4 = reinterpret_cast<const f32x4 *>(act) + (size_t)s0 * HW * 16;
+        const f32x4 *d4 = reinterpret_cast<const f32x4 *>(dy) + (size_t)s0 * HW * 16;
+#pragma unroll
+        for (int j = 0; j < WG_MAXLD; j++) {
+            const int i = tid + tz + j * TT;
+            const int which = i >= img4, ii = i - which * img4;
+            pf[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (i < 2 * img4 && (ii >> 4) < R) pf[j] = which ? d4[ii] : a4[ii];
+        }
+    };
+    auto commit = [&](int tz) {
+#pragma unroll
+        for (int j = 0; j < WG_MAXLD; j++) {
+            const int i = tid + tz + j * TT;
+            const int which = i >= img4, ii = i - which * img4;
+            if (i < 2 * img4) {
+                const int rm = rowmap[ii >> 4], c4 = ii & 15;
+                const f32x4 v = pf[j] * (which ? sD : sA);
+                union { h2v h[2]; u32x2 u; } oh, ol;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const f2v x = {v[2 * q], v[2 * q + 1]};
+                    const h2v h = __builtin_convertvector(x, h2v);
+                    oh.h[q] = h;
+                    ol.h[q] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
+                }
+                char *dst = (which ? Di + (size_t)(rm & 0xffff) * WH_SB : Ai + (size_t)(rm >> 16) * WH_SB) + c4 * 8;
+                *reinterpret_cast<u32x2 *>(dst) = oh.u;
+                *reinterpret_cast<u32x2 *>(dst + 128) = ol.u;
+            }
+        }
+    };
+    __syncthreads(); // tables, zeroed images
+    if ((int)blockIdx.x < nchunks) issue(blockIdx.x, 0);
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) toff[t] = ((t / 3) * PW + (t % 3)) * WH_SB;
+    // this lane's part of a transposed read: row 4 gq + (lane >> 2 & 3) (+ 16 for the second half of the K slots), columns 4 (lane & 3) ..
+    const int lrow = 4 * gq + ((lane >> 2) & 3), lcol = (lane & 3) * 8;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)Ai; // 32-bit LDS addresses from here on
+    const unsigned abase = lds0 + cit * 32 + lcol;
+    const unsigned dbase = lds0 + (unsigned)geo.RA * WH_SB + lrow * WH_SB + ch * 64 + lcol;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        int tz = 0;
+        asm volatile("" : "+v"(tz));
+        __syncthreads(); // the previous chunk's reads are done
+        commit(tz);
+        __syncthreads();
+        asm volatile("" : "+v"(tz));
+        if (chunk + (int)gridDim.x < nchunks) issue(chunk + gridDim.x, tz);
+        FragH ah[3], al[3];        // A fragments of three consecutive taps
+        FragH bh[2], bl[2];        // dY fragments (two cout tiles) of the K step
+        int tA0 = tabA[lrow], tA1 = tabA[lrow + 16], nA0 = 0, nA1 = 0;
+        auto loadA = [&](int slot, int t0, int t1, int t) {
+            const unsigned p0 = abase + t0 + toff[t], p1 = abase + t1 + toff[t];
+            ah[slot].s[0] = tr_read(p0); ah[slot].s[1] = tr_read(p1);
+            al[slot].s[0] = tr_read(p0 + 128); al[slot].s[1] = tr_read(p1 + 128);
+        };
+        auto loadB = [&](FragH (&h)[2], FragH (&l)[2], int k) {
+            const unsigned p = dbase + k * 32 * WH_SB;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                h[c].s[0] = tr_read(p + c * 32); h[c].s[1] = tr_read(p + c * 32 + 16 * WH_SB);
+                l[c].s[0] = tr_read(p + c * 32 + 128); l[c].s[1] = tr_read(p + c * 32 + 16 * WH_SB + 128);
+            }
+        };
+        loadA(0, tA0, tA1, 0);
+        loadA(1, tA0, tA1, 1);
+        for (int k = 0; k < NK; k++) {
+            const bool more = k + 1 < NK;
+            // (the dY fragments are single-buffered -- registers: the 52 of the HBM prefetch must stay out of scratch -- and
+            // their read latency shows once per 54 MFMAs, where the SIMD's other wave covers it)
+            loadB(bh, bl, k);
+            if (more) { nA0 = tabA[(k + 1) * 32 + lrow]; nA1 = tabA[(k + 1) * 32 + lrow + 16]; }
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                if (t + 2 < 9) loadA((t + 2) % 3, tA0, tA1, t + 2);
+                else if (more) loadA((t + 2) % 3, nA0, nA1, t + 2 - 9);
+                __builtin_amdgcn_sched_barrier(0);
+                const int sl = t % 3;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[sl].h, bh[c].h, acc[t][c], 0, 0, 0);
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[sl].h, bh[c].h, acc[t][c], 0, 0, 0);
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[sl].h, bl[c].h, acc[t][c], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tA0 = nA0; tA1 = nA1;
+        }
+    }
+    // lane holds dW[tap][cin = cit*16 + 4 gq + i][cout = (2 ch + j)*16 + m16], scaled by sA * sD
+    const float inv = 1.0f / (sA * sD);
+    float *o = part + (size_t)blockIdx.x * 9 * TC * TC;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                o[((size_t)tap * TC + cit * 16 + 4 * gq + i) * TC + (2 * ch + j) * 16 + m16] = acc[tap][j][i] * inv;
+}
+
 // sums the workgroups' partial gradients (f64) and writes torch's [cout][cin][3][3]: 64 outputs x 4 partial lanes per block
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ part, int nparts, float *__restrict__ dw)
 {
@@ -738,6 +913,10 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
         const int zu = (t->S * t->HW * S4 + 15) & ~15;
         t->conv_lds = (size_t)(zu + 3 * S4) * 16;
         t->wgrad_lds = wg_lds_bytes(t->Sw, t->H, t->W);
+        t->Swh = 1;
+        while ((t->Swh + 1) * t->HW <= 208 && wh_lds_bytes(t->Swh + 1, t->H, t->W) <= 150 * 1024) t->Swh++;
+        t->wgrad_h3_lds = wh_lds_bytes(t->Swh, t->H, t->W);
+        t->wgrad_h3 = getenv("DBAZ_TRAIN_WGRAD_F32") ? 0 : 1;
     }
     const size_t ae = act_elems(t);
     hipError_t e = hipSuccess;
@@ -760,6 +939,8 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
     t->occ2 = getenv("DBAZ_TRAIN_OCC1") ? 0 : 1;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad_h3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_h3_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad_h3<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_h3_lds);
     if (e != hipSuccess) {
         const std::string msg = hipGetErrorString(e);
         dbaz_trainer_destroy(t);
@@ -836,7 +1017,8 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
     const long long M = (long long)n * HW;
     const int grid = (n + t->S - 1) / t->S;
     const int rb = red_blocks(M);
-    const int nchunks = (n + t->Sw - 1) / t->Sw;
+    const int Sw = t->wgrad_h3 ? t->Swh : t->Sw;
+    const int nchunks = (n + Sw - 1) / Sw;
     const int wg = std::min(t->cus, nchunks);
     unsigned *dymax = t->amax + L + 1;
     int cur = 0;
@@ -851,7 +1033,14 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
                            t->sums, reinterpret_cast<f32x4 *>(t->dY), (l & 1) ? reinterpret_cast<f32x4 *>(t->G) : (f32x4 *)nullptr,
                            dymax, t->part);
         hipLaunchKernelGGL(k_dbias_fin, dim3(1), dim3(TT), 0, s, t->part, rb, g_conv_b[l]);
-        hipLaunchKernelGGL(k_wgrad, dim3(wg), dim3(TT), t->wgrad_lds, s, t->A + ae * l, t->dY, n, t->Sw, t->H, t->W, t->wg_part);
+        if (t->wgrad_h3 && t->W == 7)
+            hipLaunchKernelGGL((k_wgrad_h3<8>), dim3(wg), dim3(TT), t->wgrad_h3_lds, s, t->A + ae * l, t->dY, t->amax + l, dymax, n, Sw, t->H,
+                               t->W, t->wg_part);
+        else if (t->wgrad_h3)
+            hipLaunchKernelGGL((k_wgrad_h3<0>), dim3(wg), dim3(TT), t->wgrad_h3_lds, s, t->A + ae * l, t->dY, t->amax + l, dymax, n, Sw, t->H,
+                               t->W, t->wg_part);
+        else
+            hipLaunchKernelGGL(k_wgrad, dim3(wg), dim3(TT), t->wgrad_lds, s, t->A + ae * l, t->dY, n, Sw, t->H, t->W, t->wg_part);
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(9 * TC * TC / 64), dim3(256), 0, s, t->wg_part, wg, g_conv_w[l]);
         ConvArgs ca;
         ca.in = t->dY; ca.in_max = dymax;

@@ -14,4 +14,5 @@ rows = list(csv.DictReader(open("$out/p_kernel_stats.csv")))
 for r in rows[:22]:
     print("%-60s calls %5s avg %9.1f us total %8.1f ms" % (r["Name"].split("(")[0][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY
+rm -f $out/p_kernel_trace.csv
 cat $out/step.json
