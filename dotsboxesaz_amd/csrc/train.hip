@@ -225,11 +225,21 @@ __device__ __forceinline__ void conv_t_body(const ConvArgs &a)
     }
     const float sx = scale_from_max(*a.in_max);
     {
+        // all of this thread's rows are requested before the first one is converted (one HBM latency per workgroup, not eight)
         const f32x4 *in4 = reinterpret_cast<const f32x4 *>(a.in) + (size_t)s0 * HW * (C / 4);
         _Float16 *img = reinterpret_cast<_Float16 *>(lds);
-        for (int i = tid; i < R * (C / 4); i += TT) {
+        constexpr int NLD = 256 * (C / 4) / TT; // <= 256 rows per workgroup
+        f32x4 pf[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int i = tid + j * TT;
+            pf[j] = i < R * (C / 4) ? in4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int i = tid + j * TT;
             const int row = i >> 4, c4 = i & 15;
-            const f32x4 v = in4[i] * sx;
+            const f32x4 v = pf[j] * sx;
             union { h2v h[2]; u32x2 u; } oh, ol;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
@@ -238,9 +248,11 @@ __device__ __forceinline__ void conv_t_body(const ConvArgs &a)
                 oh.h[q] = h;
                 ol.h[q] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
             }
-            _Float16 *ph = img + (size_t)row * (S4 * 8) + c4 * 4;
-            *reinterpret_cast<u32x2 *>(ph) = oh.u;
-            *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
+            if (i < R * (C / 4)) {
+                _Float16 *ph = img + (size_t)row * (S4 * 8) + c4 * 4;
+                *reinterpret_cast<u32x2 *>(ph) = oh.u;
+                *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
+            }
         }
         if (tid < 3 * S4) X4[zu + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -364,28 +376,25 @@ __device__ __forceinline__ void block_colsum_store(double (&s)[K][4], double *pa
     }
 }
 
-// one workgroup of 512 threads (8 partial lanes x 64 channels): tot[k][c] = sum of the partials
+// the partials' totals for the 8 channels of this workgroup (grid: C/8 workgroups of 512 threads = 64 partial lanes x 8
+// channels): tot[k][c8]; a single workgroup walking 256 partials per thread took 12 us
+#define FIN_BLOCKS (TC / 8)
 template <int K>
-__device__ __forceinline__ void colsum_total(const double *part, int nparts, double (*tot)[TC] /* LDS [K][C] */)
+__device__ __forceinline__ void colsum_total(const double *part, int nparts, double (*tot)[8] /* LDS [K][8] */)
 {
-    __shared__ double red[TT / 64][K][TC];
-    const int tid = threadIdx.x, c = tid & 63, j = tid >> 6;
+    __shared__ double red[TT / 8][K][8];
+    const int tid = threadIdx.x, c8 = tid & 7, j = tid >> 3, c = blockIdx.x * 8 + c8;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        double v0 = 0.0, v1 = 0.0;
-        int bb = j;
-        for (; bb + TT / 64 < nparts; bb += 2 * (TT / 64)) {
-            v0 += part[((size_t)bb * K + k) * TC + c];
-            v1 += part[((size_t)(bb + TT / 64) * K + k) * TC + c];
-        }
-        if (bb < nparts) v0 += part[((size_t)bb * K + k) * TC + c];
-        red[j][k][c] = v0 + v1;
+        double v = 0.0;
+        for (int bb = j; bb < nparts; bb += TT / 8) v += part[((size_t)bb * K + k) * TC + c];
+        red[j][k][c8] = v;
     }
     __syncthreads();
-    if (tid < K * TC) {
-        const int k = tid / TC, cc = tid - k * TC;
+    if (tid < K * 8) {
+        const int k = tid >> 3, cc = tid & 7;
         double v = 0.0;
-        for (int jj = 0; jj < TT / 64; jj++) v += red[jj][k][cc];
+        for (int jj = 0; jj < TT / 8; jj++) v += red[jj][k][cc];
         tot[k][cc] = v;
     }
     __syncthreads();
@@ -421,12 +430,12 @@ __global__ void __launch_bounds__(TT) k_bn_stats(const f32x4 *__restrict__ y4, l
 __global__ void __launch_bounds__(TT) k_bn_stats_fin(const double *part, int nparts, long long M, float eps, float momentum, float *mean,
                                                      float *invstd, float *run_mean, float *run_var)
 {
-    __shared__ double tot[2][TC];
+    __shared__ double tot[2][8];
     colsum_total<2>(part, nparts, tot);
-    if (threadIdx.x < TC) {
-        const int c = threadIdx.x;
-        const double m = tot[0][c] / (double)M;
-        double var = tot[1][c] / (double)M - m * m;
+    if (threadIdx.x < 8) {
+        const int c8 = threadIdx.x, c = blockIdx.x * 8 + c8;
+        const double m = tot[0][c8] / (double)M;
+        double var = tot[1][c8] / (double)M - m * m;
         if (var < 0.0) var = 0.0;
         mean[c] = (float)m;
         invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -482,16 +491,16 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_sums(const f32x4 *__restrict__ dA
 
 __global__ void __launch_bounds__(TT) k_bn_bwd_sums_fin(const double *part, int nparts, double *sums, float *dbeta, float *dgamma, unsigned *zero)
 {
-    __shared__ double tot[2][TC];
+    __shared__ double tot[2][8];
     colsum_total<2>(part, nparts, tot);
-    if (threadIdx.x < TC) {
-        const int c = threadIdx.x;
-        sums[c] = tot[0][c];
-        sums[TC + c] = tot[1][c];
-        dbeta[c] = (float)tot[0][c];
-        dgamma[c] = (float)tot[1][c];
+    if (threadIdx.x < 8) {
+        const int c8 = threadIdx.x, c = blockIdx.x * 8 + c8;
+        sums[c] = tot[0][c8];
+        sums[TC + c] = tot[1][c8];
+        dbeta[c] = (float)tot[0][c8];
+        dgamma[c] = (float)tot[1][c8];
     }
-    if (threadIdx.x == 0) *zero = 0u;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *zero = 0u;
 }
 
 // backward, pass 2: dY = gamma * invstd * (g - sum(g)/M - yhat * sum(g*yhat)/M); keeps g (skip path of a block's end);
@@ -533,9 +542,9 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ d
 
 __global__ void __launch_bounds__(TT) k_dbias_fin(const double *part, int nparts, float *dbias)
 {
-    __shared__ double tot[1][TC];
+    __shared__ double tot[1][8];
     colsum_total<1>(part, nparts, tot);
-    if (threadIdx.x < TC) dbias[threadIdx.x] = (float)tot[0][threadIdx.x];
+    if (threadIdx.x < 8) dbias[blockIdx.x * 8 + threadIdx.x] = (float)tot[0][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------
@@ -986,7 +995,7 @@ extern "C" int dbaz_trainer_forward(dbaz_trainer *t, int32_t n, const float *x, 
         if (t->occ2) hipLaunchKernelGGL(k_conv_t2, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         else hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         hipLaunchKernelGGL(k_bn_stats, dim3(rb), dim3(TT), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l), M, t->part);
-        hipLaunchKernelGGL(k_bn_stats_fin, dim3(1), dim3(TT), 0, s, t->part, rb, M, t->eps, t->momentum, t->mean + l * TC,
+        hipLaunchKernelGGL(k_bn_stats_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, M, t->eps, t->momentum, t->mean + l * TC,
                            t->invstd + l * TC, run_mean ? run_mean[l] : nullptr, run_var ? run_var[l] : nullptr);
         hipLaunchKernelGGL(k_bn_apply, dim3(ab), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l),
                            (l & 1) ? reinterpret_cast<const f32x4 *>(t->A + ae * (l - 1)) : nullptr,
@@ -1028,11 +1037,11 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
         const f32x4 *ao4 = reinterpret_cast<const f32x4 *>(t->A + ae * (l + 1));
         const f32x4 *y4 = reinterpret_cast<const f32x4 *>(t->Y + ae * l);
         hipLaunchKernelGGL(k_bn_bwd_sums, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, t->part);
-        hipLaunchKernelGGL(k_bn_bwd_sums_fin, dim3(1), dim3(TT), 0, s, t->part, rb, t->sums, g_bn_b[l], g_bn_w[l], dymax);
+        hipLaunchKernelGGL(k_bn_bwd_sums_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, t->sums, g_bn_b[l], g_bn_w[l], dymax);
         hipLaunchKernelGGL(k_bn_bwd_apply, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, bn_w[l],
                            t->sums, reinterpret_cast<f32x4 *>(t->dY), (l & 1) ? reinterpret_cast<f32x4 *>(t->G) : (f32x4 *)nullptr,
                            dymax, t->part);
-        hipLaunchKernelGGL(k_dbias_fin, dim3(1), dim3(TT), 0, s, t->part, rb, g_conv_b[l]);
+        hipLaunchKernelGGL(k_dbias_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, g_conv_b[l]);
         if (t->wgrad_h3 && t->W == 7)
             hipLaunchKernelGGL((k_wgrad_h3<8>), dim3(wg), dim3(TT), t->wgrad_h3_lds, s, t->A + ae * l, t->dY, t->amax + l, dymax, n, Sw, t->H,
                                t->W, t->wg_part);

@@ -157,3 +157,50 @@ def test_trainer_errors():
     with pytest.raises(train_tower.TrainerError):
         t.backward(x[:8], v, w, v, v, v)                    # no forward pass held
     t.close()
+
+
+def test_train_steps_hip_tower_vs_torch_tower():
+    """NeuralNetWrapper.train's step (nn.py:203-221: forward, AlphaZeroLoss, backward, SGD momentum + weight decay) on a
+    64-channel ResNetZero for a few batches: residual blocks on csrc/train.hip against the same container with the blocks
+    on torch autograd.  Same initial weights and batches; losses, every parameter, the running statistics and
+    num_batches_tracked must agree to float32 noise."""
+    from dotsboxesaz_amd import nn as dnn
+    from dotsboxesaz_amd import train as T
+    params = dnn.resnet_params(6, 6, 64, 3)
+    torch.manual_seed(3)
+    m_hip = dnn.ResNetZero(params).cuda()
+    m_ref = copy.deepcopy(m_hip)
+    g = torch.Generator().manual_seed(11)
+    crit = T.AlphaZeroLoss()
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4) for m in (m_hip, m_ref)]
+    for step in range(4):
+        boards = torch.randint(0, 2, (192, 3, 7, 7), generator=g).float().cuda()
+        pi = torch.softmax(torch.randn(192, 98, generator=g), 1).cuda()
+        z = (torch.randint(0, 3, (192, 1), generator=g).float() - 1).cuda()
+        losses = []
+        for m, opt, hip in ((m_hip, opts[0], True), (m_ref, opts[1], False)):
+            m.train(True)
+            p, v = T.training_forward(m, boards, hip_tower=hip)
+            loss, (lpi, lv) = crit(p, v, pi, z)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append((loss.item(), lpi, lv))
+        assert np.allclose(losses[0], losses[1], rtol=2e-5, atol=1e-6), (step, losses)
+    sd_h, sd_r = m_hip.state_dict(), m_ref.state_dict()
+    worst = {}
+    for k in sd_r:
+        a, b = sd_h[k].double().cpu(), sd_r[k].double().cpu()
+        if "num_batches_tracked" in k:
+            assert int(a) == int(b) == 4, k
+            continue
+        worst[k] = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+    bad = {k: v for k, v in worst.items() if v > 1e-4}
+    assert not bad, (bad, max(worst.values()))
+    # evaluation mode (validation pass of the reference's loop) goes through torch with the running statistics either way
+    m_hip.train(False)
+    with torch.no_grad():
+        p, v = T.training_forward(m_hip, boards)
+    assert torch.isfinite(p).all() and torch.isfinite(v).all()
+    with pytest.raises(RuntimeError):
+        T.training_forward(m_hip, boards, hip_tower=True)   # required, but the model is in eval mode
