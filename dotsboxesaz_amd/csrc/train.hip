@@ -48,6 +48,7 @@ struct dbaz_trainer {
     float eps = 1e-5f, momentum = 0.1f;
     size_t conv_lds = 0, wgrad_lds = 0;
     bool have_fwd = false;
+    int occ2 = 1; // k_conv_t2 (two workgroups per CU)
     int wgrad_h3 = 1, Swh = 1; // k_wgrad_h3 (f16x3) and its samples per chunk; 0: the exact-f32 k_wgrad
     size_t wgrad_h3_lds = 0;
     std::string err;
@@ -186,20 +187,8 @@ __global__ void __launch_bounds__(TT) k_pack_w(PackArgs pa, _Float16 *__restrict
 // lane's own bank slot.  out = acc * 2^-(sx+sw) (+ bias) (+ add).
 // ------------------------------------------------------------------------------------
 struct ConvArgs {
-    // MODE 0 (forward): the conv input A = relu(gamma * (in - mean) * invstd + beta (+ res)) is formed while the rows are staged
-    //   (mean == nullptr: `in` IS the input) and written to stage_out; the epilogue adds the bias and leaves per-workgroup sums
-    //   of y and y^2 in part[blockIdx][2][C] (the batch statistics of THIS layer).
-    // MODE 1 (backward): in = dA of the layer's output, aout = that output, y = the layer's conv result: the staging forms
-    //   g = dA * (aout > 0), dY = gamma * invstd * (g - sum(g)/M - yhat * sum(g*yhat)/M), writes dY to stage_out (for the
-    //   weight gradient), g to g_out (skip path, optional) and per-workgroup sums of dY to part[blockIdx][1][C]; the conv runs on
-    //   dY with the transposed fragments; the epilogue adds `add`.
-    const float *in, *res, *aout, *y;
-    const float *mean, *invstd, *gamma, *beta;
-    const double *sums;       // MODE 1: [2][C] sum(g), sum(g*yhat) of the layer
-    float *stage_out, *g_out;
-    unsigned *gmax;           // atomicMax of the staged tensor's largest magnitude (the weight-gradient kernel's scale)
-    double *part;
-    long long M;              // rows of the whole batch
+    const float *in;          // [n*HW][C]
+    const unsigned *in_max;   // bits of max|in|
     const _Float16 *wpk;      // this layer's fragments
     const float *wsc;         // this layer's 2^-sw
     const float *bias;        // [C] or nullptr
@@ -208,36 +197,69 @@ struct ConvArgs {
     int n, S, H, W;
 };
 
-// sum over the 16 lanes that share lane >> 4 (the 16 rows of an accumulator tile)
-__device__ __forceinline__ double rowgroup_sum(double v)
-{
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// Persistent: a workgroup (one per CU) walks over sample groups g = blockIdx, + gridDim, ...; the rows of its NEXT group travel
-// HBM -> registers while the MFMA loop of the current one runs (the phases of a one-shot kernel -- load, MFMA, store -- do not
-// overlap, not even with two workgroups per CU, which start in lockstep: 86 us against 55 us of MFMA + 25 us of HBM time).
-template <int MODE>
-__global__ void __launch_bounds__(TT, 2) k_conv_t(ConvArgs a)
+template <int OCC>
+__device__ __forceinline__ void conv_t_body(const ConvArgs &a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float s_red[TT / 64][TC];
-    __shared__ float s_max[TT / 64];
-    constexpr int C = TC, S4 = (C + 8) / 4, KS = C / 32, LO = C / 8, N = 9 * KS, NTT = 4, RD = 2;
-    constexpr int NLD = 256 * (C / 4) / TT; // quads per thread and tensor: <= 256 rows per group
+    constexpr int C = TC, S4 = (C + 8) / 4, KS = C / 32, LO = C / 8, N = 9 * KS, NTT = 4;
     const int HW = a.H * a.W, W = a.W, H = a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ngroups = (a.n + a.S - 1) / a.S;
+    const int s0 = blockIdx.x * a.S;
+    const int ns = min(a.S, a.n - s0);
+    if (ns <= 0) return;
+    const int R = ns * HW;
     const int zu = (a.S * HW * S4 + 15) & ~15;
     f32x4 *X4 = reinterpret_cast<f32x4 *>(lds);
     const f32x4 *wpk = reinterpret_cast<const f32x4 *>(a.wpk);
     const int ct0 = (wave & 1) * 2;
-    const f32x4 *wb0_ = wpk + (size_t)ct0 * N * 2 * 64 + lane;
+    // weight fragments (L2 -> registers) run RD - 1 steps ahead in an RD-deep ring; the first RD - 1 steps are fetched before
+    // the staging so that their latency hides behind it
+    constexpr int RD = OCC == 2 ? 2 : 3;
+    const f32x4 *wb0 = wpk + (size_t)ct0 * N * 2 * 64 + lane;
+    const f32x4 *wb1 = wb0 + (size_t)N * 2 * 64;
+    u128h a_h[2][RD], a_l[2][RD];
+#pragma unroll
+    for (int j = 0; j < RD - 1; j++) {
+        a_h[0][j].f = wb0[(size_t)j * 128]; a_l[0][j].f = wb0[(size_t)j * 128 + 64];
+        a_h[1][j].f = wb1[(size_t)j * 128]; a_l[1][j].f = wb1[(size_t)j * 128 + 64];
+    }
+    const float sx = scale_from_max(*a.in_max);
+    {
+        // all of this thread's rows are requested before the first one is converted (one HBM latency per workgroup, not eight)
+        const f32x4 *in4 = reinterpret_cast<const f32x4 *>(a.in) + (size_t)s0 * HW * (C / 4);
+        _Float16 *img = reinterpret_cast<_Float16 *>(lds);
+        constexpr int NLD = 256 * (C / 4) / TT; // <= 256 rows per workgroup
+        f32x4 pf[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int i = tid + j * TT;
+            pf[j] = i < R * (C / 4) ? in4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int i = tid + j * TT;
+            const int row = i >> 4, c4 = i & 15;
+            const f32x4 v = pf[j] * sx;
+            union { h2v h[2]; u32x2 u; } oh, ol;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const f2v x = {v[2 * q], v[2 * q + 1]};
+                const h2v h = __builtin_convertvector(x, h2v);
+                oh.h[q] = h;
+                ol.h[q] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
+            }
+            if (i < R * (C / 4)) {
+                _Float16 *ph = img + (size_t)row * (S4 * 8) + c4 * 4;
+                *reinterpret_cast<u32x2 *>(ph) = oh.u;
+                *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
+            }
+        }
+        if (tid < 3 * S4) X4[zu + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
     const int jrow = lane & 15, gq = lane >> 4;
     const int tbase = (wave >> 1) * NTT;
-    int pm[NTT]; // per position tile: 9-bit mask of the taps whose source pixel lies inside the image
+    int vm[NTT];
 #pragma unroll
     for (int t = 0; t < NTT; t++) {
         const int row = (tbase + t) * 16 + jrow;
@@ -248,266 +270,87 @@ __global__ void __launch_bounds__(TT, 2) k_conv_t(ConvArgs a)
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             m |= ((yy >= 0) && (yy < H) && (xx >= 0) && (xx < W)) ? (1 << tap) : 0;
         }
-        pm[t] = m;
+        vm[t] = row < R ? m : 0;
     }
     const int rowbase = (tbase * 16 + jrow) * S4 + gq;
     const int zbase = zu;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 3 * S4) X4[zu + tid] = z4; // zero region (never overwritten)
-    const int cq_t = tid & 15; // a thread's staged elements all belong to this channel quad
-    // prefetch registers: MODE 0: in (+ res); MODE 1: dA, aout, y
-    f32x4 p0[NLD], p1[NLD], p2[MODE == 1 ? NLD : 1];
-    // (tz: an opaque zero that keeps the compiler from carrying the chunk-independent offsets of the staging across the MFMA loop)
-    auto issue = [&](int g, int tz) {
-        const int s0 = g * a.S, n4 = min(a.S, a.n - s0) * HW * (C / 4);
-        const size_t g0 = (size_t)s0 * HW * (C / 4);
-        const f32x4 *q0 = reinterpret_cast<const f32x4 *>(a.in) + g0;
+    f32x4 acc[2][NTT];
 #pragma unroll
-        for (int j = 0; j < NLD; j++) p0[j] = tid + tz + j * TT < n4 ? q0[tid + tz + j * TT] : z4;
-        if constexpr (MODE == 0) {
-            if (a.res) {
-                const f32x4 *q1 = reinterpret_cast<const f32x4 *>(a.res) + g0;
+    for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int j = 0; j < NLD; j++) p1[j] = tid + tz + j * TT < n4 ? q1[tid + tz + j * TT] : z4;
-            }
-        } else {
-            const f32x4 *q1 = reinterpret_cast<const f32x4 *>(a.aout) + g0;
-            const f32x4 *q2 = reinterpret_cast<const f32x4 *>(a.y) + g0;
+        for (int t = 0; t < NTT; t++) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u128h bh[NTT], bl[NTT];
+    const char *sb = reinterpret_cast<const char *>(lds);
+    int ab[NTT];
 #pragma unroll
-            for (int j = 0; j < NLD; j++) {
-                p1[j] = tid + tz + j * TT < n4 ? q1[tid + tz + j * TT] : z4;
-                p2[j] = tid + tz + j * TT < n4 ? q2[tid + tz + j * TT] : z4;
-            }
+    for (int t = 0; t < NTT; t++)
+        ab[t] = ((vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4) * 16;
+#pragma unroll
+    for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4);
+#pragma unroll
+    for (int t = 0; t < NTT; t++) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + LO * 16);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int cur = i % RD, nxt = (i + RD - 1) % RD;
+        const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
+        if (i + RD - 1 < N) {
+            a_h[0][nxt].f = wb0[(size_t)(i + RD - 1) * 128];
+            a_l[0][nxt].f = wb0[(size_t)(i + RD - 1) * 128 + 64];
+            a_h[1][nxt].f = wb1[(size_t)(i + RD - 1) * 128];
+            a_l[1][nxt].f = wb1[(size_t)(i + RD - 1) * 128 + 64];
         }
-    };
-    if ((int)blockIdx.x < ngroups) issue(blockIdx.x, 0);
-    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const int s0 = g * a.S, ns = min(a.S, a.n - s0), R = ns * HW, n4 = R * (C / 4);
-        const size_t g0 = (size_t)s0 * HW * (C / 4);
-        int tz = 0;
-        asm volatile("" : "+v"(tz));
-        // (opaque per group: otherwise the 72 fragment addresses of the MFMA loop are hoisted out of the group loop -- 144
-        // registers, spilled)
-        const f32x4 *wb0 = wb0_;
-        asm volatile("" : "+v"(wb0));
-        const f32x4 *wb1 = wb0 + (size_t)N * 2 * 64;
-        // first weight steps: their L2 latency hides behind the staging
-        u128h a_h[2][RD], a_l[2][RD];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < RD - 1; j++) {
-            a_h[0][j].f = wb0[(size_t)j * 128]; a_l[0][j].f = wb0[(size_t)j * 128 + 64];
-            a_h[1][j].f = wb1[(size_t)j * 128]; a_l[1][j].f = wb1[(size_t)j * 128 + 64];
+        for (int t = 0; t < NTT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[0][cur].h, bh[t].h, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[1][cur].h, bh[t].h, acc[1][t], 0, 0, 0);
         }
-        // ---- staging: form the conv input from the prefetched rows, keep it in HBM for the backward pass, (hi, lo) image in LDS
-        float sx;
-        {
-            _Float16 *img = reinterpret_cast<_Float16 *>(lds);
-            // per-channel constants of this thread's channel quad (re-read per group: 24 registers less across the MFMA loop)
-            f32x4 mu = z4, sc = z4, be = z4, ga = z4, mg = z4, mgy = z4;
-            if (MODE == 1 || a.mean) {
-                const int cq_o = cq_t + tz;
-                mu = *reinterpret_cast<const f32x4 *>(a.mean + cq_o * 4);
-                sc = *reinterpret_cast<const f32x4 *>(a.invstd + cq_o * 4);
-                ga = *reinterpret_cast<const f32x4 *>(a.gamma + cq_o * 4);
-                if constexpr (MODE == 0) {
-                    sc = sc * ga;
-                    be = *reinterpret_cast<const f32x4 *>(a.beta + cq_o * 4);
-                } else {
+        if (ni < N && nks == 0) {
+            const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
+            const int zt = zbase + ((rowbase + off) & 15);
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        mg[e] = (float)(a.sums[cq_o * 4 + e] / (double)a.M);
-                        mgy[e] = (float)(a.sums[TC + cq_o * 4 + e] / (double)a.M);
-                    }
-                }
-            }
-            if constexpr (MODE == 0) {
-                if (a.mean) {
-                    f32x4 *so4 = reinterpret_cast<f32x4 *>(a.stage_out) + g0;
-#pragma unroll
-                    for (int j = 0; j < NLD; j++) {
-                        const int i = tid + tz + j * TT;
-                        f32x4 x = (p0[j] - mu) * sc + be;
-                        if (a.res) x += p1[j];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) x[e] = fmaxf(x[e], 0.0f);
-                        p0[j] = i < n4 ? x : z4;
-                        if (i < n4) so4[i] = x;
-                    }
-                }
-            } else {
-                f32x4 *so4 = reinterpret_cast<f32x4 *>(a.stage_out) + g0;
-                f32x4 *go4 = a.g_out ? reinterpret_cast<f32x4 *>(a.g_out) + g0 : nullptr;
-                f32x4 sdy = z4;
-#pragma unroll
-                for (int j = 0; j < NLD; j++) {
-                    const int i = tid + tz + j * TT;
-                    f32x4 gg, o;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        gg[e] = p1[j][e] > 0.0f ? p0[j][e] : 0.0f;
-                        const float yh = (p2[j][e] - mu[e]) * sc[e];
-                        o[e] = ga[e] * sc[e] * (gg[e] - mg[e] - yh * mgy[e]);
-                    }
-                    if (i >= n4) o = z4;
-                    p0[j] = o;
-                    sdy += o;
-                    if (i < n4) {
-                        so4[i] = o;
-                        if (go4) go4[i] = gg;
-                    }
-                }
-                // per-group sums of dY (-> conv bias gradient): lanes that share a channel quad, then the 8 waves
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    sdy[e] += __shfl_xor(sdy[e], 16);
-                    sdy[e] += __shfl_xor(sdy[e], 32);
-                }
-                if (lane < 16) *reinterpret_cast<f32x4 *>(&s_red[wave][lane * 4]) = sdy;
-            }
-            float mx = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NLD; j++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) mx = fmaxf(mx, fabsf(p0[j][e]));
-            mx = wave_max(mx);
-            if (lane == 0) s_max[wave] = mx;
-            __syncthreads();
-            mx = 0.0f;
-#pragma unroll
-            for (int w = 0; w < TT / 64; w++) mx = fmaxf(mx, s_max[w]);
-            if (tid == 0 && a.gmax && mx > 0.0f) atomicMax(a.gmax, __float_as_uint(mx));
-            if (MODE == 1 && tid < TC) {
-                double t = 0.0;
-#pragma unroll
-                for (int w = 0; w < TT / 64; w++) t += (double)s_red[w][tid];
-                a.part[(size_t)g * TC + tid] = t;
-            }
-            sx = scale_from_max(__float_as_uint(mx)); // this group's operand scale: its own largest magnitude -> [2^13, 2^14)
-#pragma unroll
-            for (int j = 0; j < NLD; j++) {
-                const int i = tid + tz + j * TT;
-                const int row = i >> 4, c4 = i & 15;
-                const f32x4 x4 = p0[j] * sx;
-                union { h2v h[2]; u32x2 u; } oh, ol;
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const f2v x = {x4[2 * q], x4[2 * q + 1]};
-                    const h2v h = __builtin_convertvector(x, h2v);
-                    oh.h[q] = h;
-                    ol.h[q] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
-                }
-                if (i < n4) {
-                    _Float16 *ph = img + (size_t)row * (S4 * 8) + c4 * 4;
-                    *reinterpret_cast<u32x2 *>(ph) = oh.u;
-                    *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
-                }
-            }
+            for (int t = 0; t < NTT; t++) ab[t] = (((vm[t] >> ntap) & 1) ? rowbase + off : zt - t * 16 * S4) * 16;
         }
-        __syncthreads();
-        asm volatile("" : "+v"(tz));
-        if (g + (int)gridDim.x < ngroups) issue(g + gridDim.x, tz);
-        int vm[NTT];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < NTT; t++) vm[t] = (tbase + t) * 16 + jrow < R ? pm[t] : 0;
-        f32x4 acc[2][NTT];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int t = 0; t < NTT; t++) acc[c][t] = z4;
-        u128h bh[NTT], bl[NTT];
-        const char *sb = reinterpret_cast<const char *>(lds);
-        int ab[NTT];
-#pragma unroll
-        for (int t = 0; t < NTT; t++)
-            ab[t] = ((vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4) * 16;
-#pragma unroll
-        for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4);
-#pragma unroll
-        for (int t = 0; t < NTT; t++) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + LO * 16);
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            const int cur = i % RD, nxt = (i + RD - 1) % RD;
-            const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
-            if (i + RD - 1 < N) {
-                a_h[0][nxt].f = wb0[(size_t)(i + RD - 1) * 128];
-                a_l[0][nxt].f = wb0[(size_t)(i + RD - 1) * 128 + 64];
-                a_h[1][nxt].f = wb1[(size_t)(i + RD - 1) * 128];
-                a_l[1][nxt].f = wb1[(size_t)(i + RD - 1) * 128 + 64];
-            }
+        for (int t = 0; t < NTT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[0][cur].h, bh[t].h, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[1][cur].h, bh[t].h, acc[1][t], 0, 0, 0);
+            if (ni < N) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64);
             __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-            for (int t = 0; t < NTT; t++) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[0][cur].h, bh[t].h, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[1][cur].h, bh[t].h, acc[1][t], 0, 0, 0);
-            }
-            if (ni < N && nks == 0) {
-                const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
-                const int zt = zbase + ((rowbase + off) & 15);
-#pragma unroll
-                for (int t = 0; t < NTT; t++) ab[t] = (((vm[t] >> ntap) & 1) ? rowbase + off : zt - t * 16 * S4) * 16;
-            }
+        for (int t = 0; t < NTT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[0][cur].h, bl[t].h, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[1][cur].h, bl[t].h, acc[1][t], 0, 0, 0);
+            if (ni < N) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64 + LO * 16);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < NTT; t++) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[0][cur].h, bh[t].h, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[1][cur].h, bh[t].h, acc[1][t], 0, 0, 0);
-                if (ni < N) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int t = 0; t < NTT; t++) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[0][cur].h, bl[t].h, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[1][cur].h, bl[t].h, acc[1][t], 0, 0, 0);
-                if (ni < N) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64 + LO * 16);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
-        // ---- epilogue: lane holds couts (ct0 + c) * 16 + 4 gq .. +3 of position row (tbase + t) * 16 + jrow
-        const float osc = (1.0f / sx) * *a.wsc;
-        f32x4 *out4 = reinterpret_cast<f32x4 *>(a.out) + g0;
-        const f32x4 *add4 = a.add ? reinterpret_cast<const f32x4 *>(a.add) + g0 : nullptr;
-        double *sq = reinterpret_cast<double *>(lds); // MODE 0: [tile group 4][2][C] sums, in the (now idle) image
-        __syncthreads();                              // every wave has left the MFMA loop: the image may be overwritten
+    }
+    // ---- epilogue: lane holds couts (ct0 + c) * 16 + 4 gq .. +3 of position row (tbase + t) * 16 + jrow
+    const float osc = (1.0f / sx) * *a.wsc;
+    f32x4 *out4 = reinterpret_cast<f32x4 *>(a.out) + (size_t)s0 * HW * (C / 4);
+    const f32x4 *add4 = a.add ? reinterpret_cast<const f32x4 *>(a.add) + (size_t)s0 * HW * (C / 4) : nullptr;
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const int cq = (ct0 + c) * 4 + gq;
-            const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + cq * 4) : z4;
-            double sy[4] = {0.0, 0.0, 0.0, 0.0}, sy2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < 2; c++) {
+        const int cq = (ct0 + c) * 4 + gq;
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < NTT; t++) {
-                const int row = (tbase + t) * 16 + jrow;
-                if (row < R) {
-                    f32x4 v = acc[c][t] * osc + bv;
-                    if (add4) v += add4[(size_t)row * (C / 4) + cq];
-                    out4[(size_t)row * (C / 4) + cq] = v;
-                    if constexpr (MODE == 0) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) { const double d = v[e]; sy[e] += d; sy2[e] += d * d; }
-                    }
-                }
+        for (int t = 0; t < NTT; t++) {
+            const int row = (tbase + t) * 16 + jrow;
+            if (row < R) {
+                f32x4 v = acc[c][t] * osc + bv;
+                if (add4) v += add4[(size_t)row * (C / 4) + cq];
+                out4[(size_t)row * (C / 4) + cq] = v;
             }
-            if constexpr (MODE == 0) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double t1 = rowgroup_sum(sy[e]), t2 = rowgroup_sum(sy2[e]);
-                    if (jrow == 0) {
-                        sq[((wave >> 1) * 2 + 0) * TC + cq * 4 + e] = t1;
-                        sq[((wave >> 1) * 2 + 1) * TC + cq * 4 + e] = t2;
-                    }
-                }
-            }
-        }
-        if constexpr (MODE == 0) {
-            __syncthreads();
-            if (tid < 2 * TC) {
-                const int k = tid / TC, ch = tid - k * TC;
-                a.part[((size_t)g * 2 + k) * TC + ch] = (sq[(0 * 2 + k) * TC + ch] + sq[(1 * 2 + k) * TC + ch]) +
-                                                        (sq[(2 * 2 + k) * TC + ch] + sq[(3 * 2 + k) * TC + ch]);
-            }
-            __syncthreads(); // the sums are read: the next group's staging may overwrite the image
         }
     }
 }
+
+// two instantiations: 1 workgroup per CU (144 registers) or 2 (128 registers, a few spills): the second overlaps one
+// workgroup's staging and stores with the other's MFMA loop
+__global__ void __launch_bounds__(TT, 2) k_conv_t(ConvArgs a) { conv_t_body<1>(a); }
+__global__ void __launch_bounds__(TT, 4) k_conv_t2(ConvArgs a) { conv_t_body<2>(a); }
 
 // ------------------------------------------------------------------------------------
 // column sums over the rows of [M][C] tensors, f64: the workgroup's 512 threads = 32 row lanes x 16 channel quads write one
@@ -566,8 +409,21 @@ __device__ __forceinline__ void block_atomic_max(float mx, unsigned *amax)
     if (threadIdx.x == 0) {
         float m = 0.0f;
         for (int i = 0; i < (int)(blockDim.x >> 6); i++) m = fmaxf(m, s_mx[i]);
-        if (amax && m > 0.0f) atomicMax(amax, __float_as_uint(m));
+        if (m > 0.0f) atomicMax(amax, __float_as_uint(m));
     }
+}
+
+// partials of sum(y), sum(y^2) over the rows
+__global__ void __launch_bounds__(TT) k_bn_stats(const f32x4 *__restrict__ y4, long long M, double *part)
+{
+    double s[2][4] = {};
+    const int cq = threadIdx.x & 15;
+    for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += (long long)gridDim.x * 32) {
+        const f32x4 v = y4[r * 16 + cq];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const double d = v[e]; s[0][e] += d; s[1][e] += d * d; }
+    }
+    block_colsum_store<2>(s, part);
 }
 
 // -> batch mean / invstd and the running statistics (BatchNorm2d training mode: momentum 0.1, unbiased running variance)
@@ -645,6 +501,43 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_sums_fin(const double *part, int 
         dgamma[c] = (float)tot[1][c8];
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) *zero = 0u;
+}
+
+// backward, pass 2: dY = gamma * invstd * (g - sum(g)/M - yhat * sum(g*yhat)/M); keeps g (skip path of a block's end);
+// tracks max|dY|; partials of sum(dY) (the conv bias gradient: k_dbias_fin)
+__global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ dA4, const f32x4 *__restrict__ aout4, const f32x4 *__restrict__ y4,
+                                                     long long M, const float *mean, const float *invstd, const float *gamma,
+                                                     const double *sums, f32x4 *__restrict__ dY4, f32x4 *__restrict__ g4,
+                                                     unsigned *amax, double *part)
+{
+    double s[1][4] = {};
+    const int cq = threadIdx.x & 15;
+    const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cq * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + cq * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + cq * 4);
+    f32x4 mg, mgy;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        mg[e] = (float)(sums[cq * 4 + e] / (double)M);
+        mgy[e] = (float)(sums[TC + cq * 4 + e] / (double)M);
+    }
+    float mx = 0.0f;
+    for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += (long long)gridDim.x * 32) {
+        const f32x4 d = dA4[r * 16 + cq], ao = aout4[r * 16 + cq], y = y4[r * 16 + cq];
+        f32x4 g, o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            g[e] = ao[e] > 0.0f ? d[e] : 0.0f;
+            const float yh = (y[e] - mu[e]) * is[e];
+            o[e] = ga[e] * is[e] * (g[e] - mg[e] - yh * mgy[e]);
+            mx = fmaxf(mx, fabsf(o[e]));
+            s[0][e] += (double)o[e];
+        }
+        dY4[r * 16 + cq] = o;
+        if (g4) g4[r * 16 + cq] = g;
+    }
+    block_atomic_max(mx, amax);
+    block_colsum_store<1>(s, part);
 }
 
 __global__ void __launch_bounds__(TT) k_dbias_fin(const double *part, int nparts, float *dbias)
@@ -1048,12 +941,12 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     alloc((void **)&t->amax, (size_t)(t->L + 2) * 4);
     alloc((void **)&t->mean, (size_t)t->L * TC * 4);
     alloc((void **)&t->invstd, (size_t)t->L * TC * 4);
-    alloc((void **)&t->part, (size_t)std::max(RED_BLOCKS, (max_batch + t->S - 1) / t->S) * 2 * TC * 8);
+    alloc((void **)&t->part, (size_t)RED_BLOCKS * 4 * TC * 8);
     alloc((void **)&t->sums, (size_t)4 * TC * 8);
     alloc((void **)&t->wg_part, (size_t)t->cus * 9 * TC * TC * 4);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
-
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
+    t->occ2 = getenv("DBAZ_TRAIN_OCC1") ? 0 : 1;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad_h3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_h3_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad_h3<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_h3_lds);
@@ -1085,36 +978,30 @@ extern "C" int dbaz_trainer_forward(dbaz_trainer *t, int32_t n, const float *x, 
     const long long M = (long long)n * HW;
     t->have_fwd = false;
     HIPCHK(t, hipMemsetAsync(t->amax, 0, (size_t)(L + 2) * 4, s));
-    hipLaunchKernelGGL(k_nchw_to_rows, dim3(n), dim3(256), (size_t)TC * (HW + 1) * 4, s, x, t->A, HW, (unsigned *)nullptr);
+    hipLaunchKernelGGL(k_nchw_to_rows, dim3(n), dim3(256), (size_t)TC * (HW + 1) * 4, s, x, t->A, HW, t->amax);
     PackArgs pa;
     for (int l = 0; l < L; l++) pa.w[l] = conv_w[l];
     hipLaunchKernelGGL(k_pack_w, dim3(L, 2), dim3(TT), 0, s, pa, t->wpk, t->wsc, L);
-    const int grid = (n + t->S - 1) / t->S, cgrid = std::min(grid, t->cus);
+    const int grid = (n + t->S - 1) / t->S;
+    const int rb = red_blocks(M);
     const long long n4 = M * 16;
     const int ab = (int)std::min<long long>((n4 + 255) / 256, 1024);
     for (int l = 0; l < L; l++) {
-        // layer l's conv forms its own input A[l] = relu(bn(Y[l-1]) (+ A[l-2])) while staging it (l = 0: the tower input)
-        ConvArgs ca = {};
-        if (l == 0) {
-            ca.in = t->A;
-        } else {
-            ca.in = t->Y + ae * (l - 1);
-            ca.res = (l & 1) ? nullptr : t->A + ae * (l - 2);
-            ca.mean = t->mean + (l - 1) * TC; ca.invstd = t->invstd + (l - 1) * TC; ca.gamma = bn_w[l - 1]; ca.beta = bn_b[l - 1];
-            ca.stage_out = t->A + ae * l;
-        }
-        ca.gmax = t->amax + l; ca.part = t->part; ca.M = M;
+        ConvArgs ca;
+        ca.in = t->A + ae * l; ca.in_max = t->amax + l;
         ca.wpk = t->wpk + (size_t)l * TC * TC * 9 * 2; ca.wsc = t->wsc + l;
-        ca.bias = conv_b[l]; ca.out = t->Y + ae * l;
+        ca.bias = conv_b[l]; ca.add = nullptr; ca.out = t->Y + ae * l;
         ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
-        hipLaunchKernelGGL((k_conv_t<0>), dim3(cgrid), dim3(TT), t->conv_lds, s, ca);
-        hipLaunchKernelGGL(k_bn_stats_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, grid, M, t->eps, t->momentum, t->mean + l * TC,
+        if (t->occ2) hipLaunchKernelGGL(k_conv_t2, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        else hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        hipLaunchKernelGGL(k_bn_stats, dim3(rb), dim3(TT), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l), M, t->part);
+        hipLaunchKernelGGL(k_bn_stats_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, M, t->eps, t->momentum, t->mean + l * TC,
                            t->invstd + l * TC, run_mean ? run_mean[l] : nullptr, run_var ? run_var[l] : nullptr);
+        hipLaunchKernelGGL(k_bn_apply, dim3(ab), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l),
+                           (l & 1) ? reinterpret_cast<const f32x4 *>(t->A + ae * (l - 1)) : nullptr,
+                           reinterpret_cast<f32x4 *>(t->A + ae * (l + 1)), n4, t->mean + l * TC, t->invstd + l * TC, bn_w[l], bn_b[l],
+                           t->amax + l + 1);
     }
-    // the tower's output: relu(bn(Y[L-1]) + A[L-2])
-    hipLaunchKernelGGL(k_bn_apply, dim3(ab), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * (L - 1)),
-                       reinterpret_cast<const f32x4 *>(t->A + ae * (L - 2)), reinterpret_cast<f32x4 *>(t->A + ae * L), n4,
-                       t->mean + (L - 1) * TC, t->invstd + (L - 1) * TC, bn_w[L - 1], bn_b[L - 1], (unsigned *)nullptr);
     hipLaunchKernelGGL(k_rows_to_nchw, dim3(n), dim3(256), (size_t)HW * (TC + 1) * 4, s, t->A + ae * L, out, HW);
     HIPCHK(t, hipGetLastError());
     t->n = n;
@@ -1137,7 +1024,7 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
     const int L = t->L, HW = t->HW, n = t->n;
     const size_t ae = act_elems(t);
     const long long M = (long long)n * HW;
-    const int grid = (n + t->S - 1) / t->S, cgrid = std::min(grid, t->cus);
+    const int grid = (n + t->S - 1) / t->S;
     const int rb = red_blocks(M);
     const int Sw = t->wgrad_h3 ? t->Swh : t->Sw;
     const int nchunks = (n + Sw - 1) / Sw;
@@ -1151,18 +1038,10 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
         const f32x4 *y4 = reinterpret_cast<const f32x4 *>(t->Y + ae * l);
         hipLaunchKernelGGL(k_bn_bwd_sums, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, t->part);
         hipLaunchKernelGGL(k_bn_bwd_sums_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, t->sums, g_bn_b[l], g_bn_w[l], dymax);
-        // the transposed conv forms dY[l] while staging it (and leaves it in HBM for the weight gradient)
-        ConvArgs ca = {};
-        ca.in = t->dA[cur]; ca.aout = t->A + ae * (l + 1); ca.y = t->Y + ae * l;
-        ca.mean = t->mean + l * TC; ca.invstd = t->invstd + l * TC; ca.gamma = bn_w[l]; ca.sums = t->sums;
-        ca.stage_out = t->dY; ca.g_out = (l & 1) ? t->G : nullptr;
-        ca.gmax = dymax; ca.part = t->part; ca.M = M;
-        ca.wpk = t->wpk + ((size_t)L + l) * TC * TC * 9 * 2; ca.wsc = t->wsc + L + l;
-        ca.bias = nullptr; ca.out = t->dA[1 - cur];
-        ca.add = (l & 1) ? nullptr : t->G; // the input of a block's first conv is also the block's skip input: + g of its end
-        ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
-        hipLaunchKernelGGL((k_conv_t<1>), dim3(cgrid), dim3(TT), t->conv_lds, s, ca);
-        hipLaunchKernelGGL(k_dbias_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, grid, g_conv_b[l]);
+        hipLaunchKernelGGL(k_bn_bwd_apply, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, bn_w[l],
+                           t->sums, reinterpret_cast<f32x4 *>(t->dY), (l & 1) ? reinterpret_cast<f32x4 *>(t->G) : (f32x4 *)nullptr,
+                           dymax, t->part);
+        hipLaunchKernelGGL(k_dbias_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, g_conv_b[l]);
         if (t->wgrad_h3 && t->W == 7)
             hipLaunchKernelGGL((k_wgrad_h3<8>), dim3(wg), dim3(TT), t->wgrad_h3_lds, s, t->A + ae * l, t->dY, t->amax + l, dymax, n, Sw, t->H,
                                t->W, t->wg_part);
@@ -1172,6 +1051,14 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
         else
             hipLaunchKernelGGL(k_wgrad, dim3(wg), dim3(TT), t->wgrad_lds, s, t->A + ae * l, t->dY, n, Sw, t->H, t->W, t->wg_part);
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(9 * TC * TC / 64), dim3(256), 0, s, t->wg_part, wg, g_conv_w[l]);
+        ConvArgs ca;
+        ca.in = t->dY; ca.in_max = dymax;
+        ca.wpk = t->wpk + ((size_t)L + l) * TC * TC * 9 * 2; ca.wsc = t->wsc + L + l;
+        ca.bias = nullptr; ca.out = t->dA[1 - cur];
+        ca.add = (l & 1) ? nullptr : t->G; // the input of a block's first conv is also the block's skip input: + g of its end
+        ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
+        if (t->occ2) hipLaunchKernelGGL(k_conv_t2, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        else hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         cur = 1 - cur;
     }
     hipLaunchKernelGGL(k_rows_to_nchw, dim3(n), dim3(256), (size_t)HW * (TC + 1) * 4, s, t->dA[cur], grad_x, HW);
