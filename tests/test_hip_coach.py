@@ -68,3 +68,45 @@ def test_three_generations_on_3x3(tmp_path):
     p_hip, v_hip = coach.engine.predict(x)
     assert np.max(np.abs(p_hip - np.exp(lp.numpy()))) < 1e-4 and np.max(np.abs(v_hip - v.numpy())) < 1e-4
     coach.close()
+
+
+def test_generation_loop_trains_through_the_hip_tower(tmp_path):
+    """The same loop with a 64-channel ResNetZero: train.train() sends the residual blocks through csrc/train.hip
+    (dbaz_trainer_*), the rest of the step through torch; the weights it produces drive the next generation's self-play."""
+    import torch
+    from dotsboxesaz_amd import nn as dnn
+    from dotsboxesaz_amd import train as T
+    from dotsboxesaz_amd import train_tower
+    from dotsboxesaz_amd.coach import Coach
+    params = dnn.resnet_params(3, 3, 64, 2, 4, 8)
+    params["nn"]["model_class"] = dnn.ResNetZero
+    params["nn"]["chkpts_filename"] = str(tmp_path / "model_gen{}.pt")
+    params["nn"]["train_params"] = {"nb_epochs": 2, "train_batch_size": 128, "val_batch_size": 32, "lr": 1e-2,
+                                    "lr_scheduler": T.GenerationLrScheduler({0: 1e-2}),
+                                    "optimizer_params": {"momentum": 0.9, "weight_decay": 1e-4},
+                                    "pos_average": True, "train_split": 0.9, "max_samples_per_gen": 100000, "symmetries": None}
+    params["self_play"] = {"num_games": 96, "reuse_mcts_tree": True, "noise": (0.8, 0.25),
+                           "mcts": {"mcts_num_read": 24, "mcts_cpuct": (1.25, 19652), "temperature": {0: 1.0, 6: 0.02}}}
+    params["elo"] = {"n_games": 8, "self_play_override": {"reuse_mcts_tree": False, "noise": (0.0, 0.0), "mcts": {"mcts_num_read": 16}}}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    train_tower._trainers.clear()
+    coach = Coach(params, 3, 3, n_slots=32)
+    w = Writer()
+    log = coach.learn_to_play(0, 1, writer=w)
+    assert [r["generation"] for r in log] == [0, 1] and log[1]["last_batch_idx"] > 0
+    assert len(train_tower._trainers) == 1                        # the HIP tower ran the training steps
+    losses = [v for t, v, _ in w.s if t == "loss/total/train"]
+    assert len(losses) == log[1]["last_batch_idx"] and np.all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3])
+    ck = torch.load(params["nn"]["chkpts_filename"].format(1), map_location="cpu", weights_only=True)
+    model = dnn.ResNetZero(params)
+    model.load_state_dict(ck["model_dict"])
+    assert int(ck["model_dict"]["resnet.resblocks.0.bn1.num_batches_tracked"]) == log[1]["last_batch_idx"]
+    model.train(False)
+    x = np.random.RandomState(1).randint(0, 2, size=(64, 3, 4, 4)).astype(np.float32)
+    x[:, 2] = 4.0
+    with torch.no_grad():
+        lp, v = T.training_forward(model, torch.tensor(x))
+    p_hip, v_hip = coach.engine.predict(x)                        # the engine holds the weights the HIP tower trained
+    assert np.max(np.abs(p_hip - np.exp(lp.numpy()))) < 1e-4 and np.max(np.abs(v_hip - v.numpy())) < 1e-4
+    coach.close()
