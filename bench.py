@@ -276,6 +276,33 @@ def single_tree_bench(args, local_rank, torch):
     print(json.dumps(out), flush=True)
 
 
+def train_step_bench(args, local_rank):
+    """NeuralNetWrapper.train's step (nn.py:203-221) at the reference's batch size (configuration.py:61), residual
+    tower on the HIP kernels of csrc/train.hip against the same step with the tower on torch (MIOpen)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import train_step_time as TS
+    batch = 4096
+    hip = TS.measure(batch, True, args.train_step, args.board, args.channels, args.blocks, local_rank)
+    ref = TS.measure(batch, False, max(3, args.train_step // 2), args.board, args.channels, args.blocks, local_rank)
+    HW = (args.board + 1) ** 2
+    # conv3x3 forward + input gradient + weight gradient of the 2*blocks tower layers (2*MAC each), counted once
+    flops = 3.0 * 2 * args.blocks * 2.0 * batch * HW * args.channels * args.channels * 9
+    tf = flops / (hip["ms_per_step"] * 1e-3) / 1e12
+    out = {"metric": "train_samples_per_sec", "value": hip["samples_per_sec"], "unit": "samples/s", "n_gpus": 1, "steps": args.train_step,
+           "ms_per_step": hip["ms_per_step"], "higher_is_better": True, "vs_baseline": None,
+           "dtype": "f32 via f16x3 (hi,lo)-split MFMA (tower convs), f64 batch statistics; f32 torch for heads / loss / SGD",
+           "data": "synthetic", "config": {"workload": "%dx%d, ResNetZero %dx%d, batch %d, SGD momentum 0.9 wd 1e-4, batches from k_make_batch"
+                                           % (args.board, args.board, args.blocks, args.channels, batch)},
+           "torch_tower": {"ms_per_step": ref["ms_per_step"], "samples_per_sec": ref["samples_per_sec"]},
+           "speedup_vs_torch_tower": ref["ms_per_step"] / hip["ms_per_step"],
+           "roofline": {"bound": "mfma", "kernel": "k_conv_t + k_wgrad_h3 (tower conv forward, input gradient, weight gradient), whole step in the time",
+                        "achieved": tf, "peak": 2500.0 / 3, "unit": "TFLOP/s", "frac": tf / (2500.0 / 3), "flops_per_step": flops,
+                        "traffic": None,
+                        "note": "the step moves ~32 GB of activations through HBM (4 ms at peak): the elementwise passes and the convs' "
+                                "un-overlapped load/store phases, not the MFMA pipe, set the time (DESIGN 5.5)"}}
+    print(json.dumps(out), flush=True)
+
+
 def train_data_bench(args, local_rank, torch):
     """Training DATA path on synthetic replay rows resident in HBM: dataset build
     (stage + stable radix sort + Kahan group means = HDFStoreDataset with pos_average) and batch
@@ -405,6 +432,9 @@ def main():
     ap.add_argument("--train-data", type=int, default=0,
                     help="instead of the self-play step: time the training data path (dataset build + batch assembly) "
                          "on this many synthetic replay rows in HBM (one JSON line, metric train_data_rows_per_sec)")
+    ap.add_argument("--train-step", type=int, default=0,
+                    help="instead of the self-play step: time this many optimizer steps (batch 4096, the --board / --channels / --blocks "
+                         "network) with the residual tower on csrc/train.hip and on torch (one JSON line, metric train_samples_per_sec)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -412,7 +442,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.fresh_population:
         args.population = "fresh"
-    special = args.full_games > 0 or args.train_data > 0 or args.single_tree > 0
+    special = args.full_games > 0 or args.train_data > 0 or args.single_tree > 0 or args.train_step > 0
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not special:
         # before anything touches the GPU: the baseline forks one worker process per host core
@@ -429,6 +459,9 @@ def main():
         return
     if args.train_data > 0:
         train_data_bench(args, local_rank, torch)
+        return
+    if args.train_step > 0:
+        train_step_bench(args, local_rank)
         return
     if args.single_tree > 0:
         single_tree_bench(args, local_rank, torch)

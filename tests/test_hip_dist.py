@@ -91,6 +91,12 @@ def test_bench_train_data_mode():
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
 
 
+def test_bench_train_step_mode():
+    d = _bench("--train-step", "3", "--board", "3", "--blocks", "2")
+    assert d["metric"] == "train_samples_per_sec" and d["value"] > 0 and d["torch_tower"]["ms_per_step"] > 0
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "mfma"
+
+
 # ---- world_size 2 through the real engine: two processes share the one GPU of the box, the packed rows are
 # exchanged with a host-staged gloo all-gather (RCCL cannot put two ranks on one device)
 _CHILD2 = r"""
