@@ -118,9 +118,15 @@ __global__ void __launch_bounds__(256) k_nchw_to_rows(const float *__restrict__ 
         const int p = i >> 6, c = i & 63;
         dst[i] = sm[c * (HW + 1) + p];
     }
-    if (amax) {
+    if (amax) { // one atomic per workgroup (one per wave of 4 096 workgroups serialises for 160 us)
+        __shared__ float s_mx[4];
         mx = wave_max(mx);
-        if ((tid & 63) == 0 && mx > 0.0f) atomicMax(amax, __float_as_uint(mx));
+        if ((tid & 63) == 0) s_mx[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            const float m = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+            if (m > 0.0f) atomicMax(amax, __float_as_uint(m));
+        }
     }
 }
 
@@ -327,10 +333,12 @@ __device__ __forceinline__ void conv_t_body(const ConvArgs &a)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // ---- epilogue: lane holds couts (ct0 + c) * 16 + 4 gq .. +3 of position row (tbase + t) * 16 + jrow
+    // ---- epilogue: lane holds couts (ct0 + c) * 16 + 4 gq .. +3 of position row (tbase + t) * 16 + jrow.  The results go
+    // through the (now idle) LDS image as f32 rows of C + 4 dwords and leave as whole 256-byte rows: written straight from the
+    // accumulator layout they were 64-byte pieces of 16 different rows per instruction (13 us of a 55 us launch)
     const float osc = (1.0f / sx) * *a.wsc;
-    f32x4 *out4 = reinterpret_cast<f32x4 *>(a.out) + (size_t)s0 * HW * (C / 4);
-    const f32x4 *add4 = a.add ? reinterpret_cast<const f32x4 *>(a.add) + (size_t)s0 * HW * (C / 4) : nullptr;
+    constexpr int OS = C + 4; // dwords per staged output row: the 16 rows of a tile fall on disjoint banks
+    __syncthreads();          // every wave has left the MFMA loop
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int cq = (ct0 + c) * 4 + gq;
@@ -338,11 +346,18 @@ __device__ __forceinline__ void conv_t_body(const ConvArgs &a)
 #pragma unroll
         for (int t = 0; t < NTT; t++) {
             const int row = (tbase + t) * 16 + jrow;
-            if (row < R) {
-                f32x4 v = acc[c][t] * osc + bv;
-                if (add4) v += add4[(size_t)row * (C / 4) + cq];
-                out4[(size_t)row * (C / 4) + cq] = v;
-            }
+            if (row < R) *reinterpret_cast<f32x4 *>(lds + (size_t)row * OS + cq * 4) = acc[c][t] * osc + bv;
+        }
+    }
+    __syncthreads();
+    {
+        const size_t g0 = (size_t)s0 * HW * (C / 4);
+        f32x4 *out4 = reinterpret_cast<f32x4 *>(a.out) + g0;
+        const f32x4 *add4 = a.add ? reinterpret_cast<const f32x4 *>(a.add) + g0 : nullptr;
+        for (int i = tid; i < R * (C / 4); i += TT) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(lds + (size_t)(i >> 4) * OS + (i & 15) * 4);
+            if (add4) v += add4[i];
+            out4[i] = v;
         }
     }
 }
@@ -376,26 +391,26 @@ __device__ __forceinline__ void block_colsum_store(double (&s)[K][4], double *pa
     }
 }
 
-// the partials' totals for the 8 channels of this workgroup (grid: C/8 workgroups of 512 threads = 64 partial lanes x 8
-// channels): tot[k][c8]; a single workgroup walking 256 partials per thread took 12 us
-#define FIN_BLOCKS (TC / 8)
+// the partials' totals of channel blockIdx.x (grid: C workgroups of 512 threads, one partial lane each): tot[k]
+#define FIN_BLOCKS TC
 template <int K>
-__device__ __forceinline__ void colsum_total(const double *part, int nparts, double (*tot)[8] /* LDS [K][8] */)
+__device__ __forceinline__ void colsum_total(const double *part, int nparts, double *tot /* LDS [K] */)
 {
-    __shared__ double red[TT / 8][K][8];
-    const int tid = threadIdx.x, c8 = tid & 7, j = tid >> 3, c = blockIdx.x * 8 + c8;
+    __shared__ double red[TT / 64][K];
+    const int tid = threadIdx.x, c = blockIdx.x;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         double v = 0.0;
-        for (int bb = j; bb < nparts; bb += TT / 8) v += part[((size_t)bb * K + k) * TC + c];
-        red[j][k][c8] = v;
+        for (int bb = tid; bb < nparts; bb += TT) v += part[((size_t)bb * K + k) * TC + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) red[tid >> 6][k] = v;
     }
     __syncthreads();
-    if (tid < K * 8) {
-        const int k = tid >> 3, cc = tid & 7;
+    if (tid < K) {
         double v = 0.0;
-        for (int jj = 0; jj < TT / 8; jj++) v += red[jj][k][cc];
-        tot[k][cc] = v;
+        for (int w = 0; w < TT / 64; w++) v += red[w][tid];
+        tot[tid] = v;
     }
     __syncthreads();
 }
@@ -430,12 +445,12 @@ __global__ void __launch_bounds__(TT) k_bn_stats(const f32x4 *__restrict__ y4, l
 __global__ void __launch_bounds__(TT) k_bn_stats_fin(const double *part, int nparts, long long M, float eps, float momentum, float *mean,
                                                      float *invstd, float *run_mean, float *run_var)
 {
-    __shared__ double tot[2][8];
+    __shared__ double tot[2];
     colsum_total<2>(part, nparts, tot);
-    if (threadIdx.x < 8) {
-        const int c8 = threadIdx.x, c = blockIdx.x * 8 + c8;
-        const double m = tot[0][c8] / (double)M;
-        double var = tot[1][c8] / (double)M - m * m;
+    if (threadIdx.x == 0) {
+        const int c = blockIdx.x;
+        const double m = tot[0] / (double)M;
+        double var = tot[1] / (double)M - m * m;
         if (var < 0.0) var = 0.0;
         mean[c] = (float)m;
         invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -491,14 +506,14 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_sums(const f32x4 *__restrict__ dA
 
 __global__ void __launch_bounds__(TT) k_bn_bwd_sums_fin(const double *part, int nparts, double *sums, float *dbeta, float *dgamma, unsigned *zero)
 {
-    __shared__ double tot[2][8];
+    __shared__ double tot[2];
     colsum_total<2>(part, nparts, tot);
-    if (threadIdx.x < 8) {
-        const int c8 = threadIdx.x, c = blockIdx.x * 8 + c8;
-        sums[c] = tot[0][c8];
-        sums[TC + c] = tot[1][c8];
-        dbeta[c] = (float)tot[0][c8];
-        dgamma[c] = (float)tot[1][c8];
+    if (threadIdx.x == 0) {
+        const int c = blockIdx.x;
+        sums[c] = tot[0];
+        sums[TC + c] = tot[1];
+        dbeta[c] = (float)tot[0];
+        dgamma[c] = (float)tot[1];
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) *zero = 0u;
 }
@@ -542,9 +557,9 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ d
 
 __global__ void __launch_bounds__(TT) k_dbias_fin(const double *part, int nparts, float *dbias)
 {
-    __shared__ double tot[1][8];
+    __shared__ double tot[1];
     colsum_total<1>(part, nparts, tot);
-    if (threadIdx.x < 8) dbias[blockIdx.x * 8 + threadIdx.x] = (float)tot[0][threadIdx.x];
+    if (threadIdx.x == 0) dbias[blockIdx.x] = (float)tot[0];
 }
 
 // ------------------------------------------------------------------------------------

@@ -111,11 +111,12 @@ def resblocks_forward(model, x):
             tr.close()
         tr = TowerTrainer(H - 1, W - 1, 64, len(blocks), max(int(x.shape[0]), 1), x.device.index or 0)
         _trainers[key] = tr
-    params, rm, rv = [], [], []
+    params, rm, rv, nbt = [], [], [], []
     for b in blocks:
         for conv, bn in ((b.conv1, b.bn1), (b.conv2, b.bn2)):
             params += [conv.weight, conv.bias, bn.weight, bn.bias]
             rm.append(bn.running_mean)
             rv.append(bn.running_var)
-            bn.num_batches_tracked += 1
+            nbt.append(bn.num_batches_tracked)
+    torch._foreach_add_(nbt, 1)   # one launch for the 2*blocks counters (BatchNorm2d.forward: num_batches_tracked += 1)
     return _TowerFn.apply(tr, rm, rv, x, *params)
