@@ -45,6 +45,14 @@ def main(src, dst):
         gui = t.get("GRBM_GUI_ACTIVE", {}).get("mean")
         if busy and gui:
             out["mfma_busy_frac"] = busy / (gui / 8.0 * 1024.0)  # 8 XCDs summed; 256 CUs x 4 SIMDs
+    # per-kernel traffic and MFMA busy fraction for every kernel that has the counters (training-step runs: no k_tower)
+    for k, t in out["kernels"].items():
+        fetch, write = t.get("FETCH_SIZE", {}).get("mean"), t.get("WRITE_SIZE", {}).get("mean")
+        if fetch is not None and write is not None:
+            t["traffic_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
+        busy, gui = t.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("mean"), t.get("GRBM_GUI_ACTIVE", {}).get("mean")
+        if busy and gui:
+            t["mfma_busy_frac"] = busy / (gui / 8.0 * 1024.0)
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps({k: out.get(k) for k in ("traffic_bytes_per_launch", "mfma_busy_frac")}))
 
