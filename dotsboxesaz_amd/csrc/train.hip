@@ -13,7 +13,7 @@
 //              A[l+1] = relu(bn(Y[l]) (+ A[l-1] for the second conv of a block))   k_bn_apply
 //   backward   g = dA[l+1] * (A[l+1] > 0); sums of g and g*yhat      k_bn_bwd_sums (-> dgamma, dbeta)
 //              dY[l] = gamma*invstd*(g - mean(g) - yhat*mean(g*yhat)) k_bn_bwd_apply (also keeps g for the skip path)
-//              dW[l] = sum_rows A[l](row + tap) x dY[l](row)          k_wgrad (exact f32 MFMA) + k_wgrad_reduce
+//              dW[l] = sum_rows A[l](row + tap) x dY[l](row)          k_wgrad_h3 (f16x3 MFMA; k_wgrad: exact f32) + k_wgrad_reduce
 //              dA[l] = conv3x3^T(dY[l]) (+ g of the block's end)      k_conv_t with flipped / transposed fragments
 // Every f32 operand of k_conv_t is an error-compensated (hi, lo) pair of halves scaled by a power of two taken from the
 // tensor's own maximum (tracked by the kernel that produced it), so gradients of any magnitude keep f32-grade products.
