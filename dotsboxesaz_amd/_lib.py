@@ -26,6 +26,7 @@ SYMBOLS = [
     "dbaz_replay_rows_clear", "dbaz_dataset_select", "dbaz_dataset_begin", "dbaz_dataset_add_rows", "dbaz_dataset_finish", "dbaz_dataset_fetch", "dbaz_dataset_batch",
     "dbaz_symmetry_apply", "dbaz_symmetry_table",
     "dbaz_trainer_last_error", "dbaz_trainer_create", "dbaz_trainer_destroy", "dbaz_trainer_forward", "dbaz_trainer_backward",
+    "dbaz_bn2d_workspace_bytes", "dbaz_bn2d_forward", "dbaz_bn2d_backward",
 ]
 
 
@@ -125,10 +126,14 @@ def load():
     L.dbaz_trainer_destroy.restype = None
     L.dbaz_trainer_forward.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.dbaz_trainer_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.dbaz_bn2d_workspace_bytes.argtypes = [i32]
+    L.dbaz_bn2d_forward.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp]
+    L.dbaz_bn2d_backward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("dbaz_last_error", "dbaz_destroy", "dbaz_trainer_last_error", "dbaz_trainer_destroy"):
+        if name not in ("dbaz_last_error", "dbaz_destroy", "dbaz_trainer_last_error", "dbaz_trainer_destroy", "dbaz_bn2d_workspace_bytes"):
             fn.restype = C.c_int
+    L.dbaz_bn2d_workspace_bytes.restype = C.c_int64
     _lib = L
     return L
 

@@ -1081,3 +1081,187 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
     t->have_fwd = false;
     return DBAZ_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Training-mode BatchNorm2d (+ optional ReLU) on torch's NCHW tensors with any channel count: bn_input (3 channels), bn0 (64)
+// and the heads' bn0 (16) of ResNetZero (nn.py:19-21,81-83,98-100,114).  MIOpen's kernels for these shapes take 114 us forward
+// and 157 us backward per layer (one workgroup per channel); these are 4 launches of many small workgroups.
+// Element (n, c, p) lives at (n * C + c) * HW + p; a workgroup of 64 x 8 threads handles channel blockIdx.x and the samples
+// n = blockIdx.y * 8 + threadIdx.y (+ gridDim.y * 8 ...), lane x = position p (+ 64 ...).  Partial sums in f64: part[c][blockIdx.y][K].
+// ------------------------------------------------------------------------------------
+#define BN_NB 64 // sample slices (blockIdx.y) per channel
+
+template <int K>
+__device__ __forceinline__ void bn2d_block_store(double (&s)[K], double *part, int C)
+{
+    __shared__ double red[8][K];
+    const int lane = threadIdx.x, w = threadIdx.y;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double v = s[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[w][k] = v;
+    }
+    __syncthreads();
+    if (w == 0 && lane < K) {
+        double v = 0.0;
+        for (int i = 0; i < 8; i++) v += red[i][lane];
+        part[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * K + lane] = v;
+    }
+}
+
+__global__ void __launch_bounds__(512) k_bn2d_stats(const float *__restrict__ x, int n, int C, int HW, double *part)
+{
+    const int c = blockIdx.x;
+    double s[2] = {0.0, 0.0};
+    for (int i = blockIdx.y * 8 + threadIdx.y; i < n; i += gridDim.y * 8)
+        for (int p = threadIdx.x; p < HW; p += 64) {
+            const double v = x[((size_t)i * C + c) * HW + p];
+            s[0] += v;
+            s[1] += v * v;
+        }
+    bn2d_block_store<2>(s, part, C);
+}
+
+// one workgroup of 64 threads per channel: totals of the K partial sums -> tot[k] (all lanes)
+template <int K>
+__device__ __forceinline__ void bn2d_total(const double *part, int nb, double (&tot)[K])
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double v = 0.0;
+        for (int b = lane; b < nb; b += 64) v += part[((size_t)c * nb + b) * K + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        tot[k] = v;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_bn2d_stats_fin(const double *part, int nb, long long M, float eps, float momentum, float *mean,
+                                                       float *invstd, float *run_mean, float *run_var)
+{
+    double tot[2];
+    bn2d_total<2>(part, nb, tot);
+    if (threadIdx.x == 0) {
+        const int c = blockIdx.x;
+        const double m = tot[0] / (double)M;
+        double var = tot[1] / (double)M - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + (double)momentum * m);
+        if (run_var) {
+            const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + (double)momentum * unb);
+        }
+    }
+}
+
+// out = gamma * (x - mean) * invstd + beta, ReLU if asked; rows r = n * C + c of HW floats, 8 rows per workgroup pass
+__global__ void __launch_bounds__(512) k_bn2d_apply(const float *__restrict__ x, float *__restrict__ out, long long rows, int C, int HW,
+                                                    const float *mean, const float *invstd, const float *gamma, const float *beta, int relu)
+{
+    for (long long r = (long long)blockIdx.x * 8 + threadIdx.y; r < rows; r += (long long)gridDim.x * 8) {
+        const int c = (int)(r % C);
+        const float mu = mean[c], sc = invstd[c] * gamma[c], be = beta[c];
+        for (int p = threadIdx.x; p < HW; p += 64) {
+            float v = (x[r * HW + p] - mu) * sc + be;
+            if (relu) v = fmaxf(v, 0.0f);
+            out[r * HW + p] = v;
+        }
+    }
+}
+
+// backward sums: g = dout * (out > 0 if relu); sum(g), sum(g * xhat)
+__global__ void __launch_bounds__(512) k_bn2d_bwd_sums(const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ x,
+                                                       int n, int C, int HW, const float *mean, const float *invstd, int relu, double *part)
+{
+    const int c = blockIdx.x;
+    double s[2] = {0.0, 0.0};
+    const float mu = mean[c], is = invstd[c];
+    for (int i = blockIdx.y * 8 + threadIdx.y; i < n; i += gridDim.y * 8)
+        for (int p = threadIdx.x; p < HW; p += 64) {
+            const size_t o = ((size_t)i * C + c) * HW + p;
+            float g = dout[o];
+            if (relu && !(out[o] > 0.0f)) g = 0.0f;
+            s[0] += (double)g;
+            s[1] += (double)g * (double)((x[o] - mu) * is);
+        }
+    bn2d_block_store<2>(s, part, C);
+}
+
+__global__ void __launch_bounds__(64) k_bn2d_bwd_fin(const double *part, int nb, double *sums /*[C][2]*/, float *dgamma, float *dbeta)
+{
+    double tot[2];
+    bn2d_total<2>(part, nb, tot);
+    if (threadIdx.x == 0) {
+        const int c = blockIdx.x;
+        sums[c * 2] = tot[0];
+        sums[c * 2 + 1] = tot[1];
+        dbeta[c] = (float)tot[0];
+        dgamma[c] = (float)tot[1];
+    }
+}
+
+__global__ void __launch_bounds__(512) k_bn2d_bwd_apply(const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ x,
+                                                        float *__restrict__ dx, long long rows, long long M, int C, int HW, const float *mean,
+                                                        const float *invstd, const float *gamma, const double *sums, int relu)
+{
+    for (long long r = (long long)blockIdx.x * 8 + threadIdx.y; r < rows; r += (long long)gridDim.x * 8) {
+        const int c = (int)(r % C);
+        const float mu = mean[c], is = invstd[c], gi = gamma[c] * is;
+        const float mg = (float)(sums[c * 2] / (double)M), mgy = (float)(sums[c * 2 + 1] / (double)M);
+        for (int p = threadIdx.x; p < HW; p += 64) {
+            float g = dout[r * HW + p];
+            if (relu && !(out[r * HW + p] > 0.0f)) g = 0.0f;
+            const float xh = (x[r * HW + p] - mu) * is;
+            dx[r * HW + p] = gi * (g - mg - xh * mgy);
+        }
+    }
+}
+
+// workspace (caller-owned DEVICE memory, 8-byte aligned): C * BN_NB * 2 doubles of partials + C * 2 doubles of sums
+extern "C" int64_t dbaz_bn2d_workspace_bytes(int32_t channels) { return (int64_t)channels * (BN_NB * 2 + 2) * 8; }
+
+// Training-mode BatchNorm2d forward on x [n][C][H*W] (NCHW, contiguous): out = relu?(gamma * xhat + beta); saves the batch mean /
+// invstd ([C] each) for the backward call, updates run_mean / run_var in place (NULL: skip).  Asynchronous on `stream`.
+extern "C" int dbaz_bn2d_forward(const float *x, int32_t n, int32_t channels, int32_t hw, const float *gamma, const float *beta,
+                                 float *run_mean, float *run_var, float eps, float momentum, int32_t relu, float *out, float *save_mean,
+                                 float *save_invstd, void *workspace, void *stream)
+{
+    if (!x || !gamma || !beta || !out || !save_mean || !save_invstd || !workspace) return terr(nullptr, DBAZ_EINVAL, "null argument");
+    if (n < 1 || channels < 1 || hw < 1) return terr(nullptr, DBAZ_EINVAL, "bn2d: n, channels and H*W must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    double *part = reinterpret_cast<double *>(workspace);
+    const int nb = std::min(BN_NB, (n + 7) / 8);
+    const long long rows = (long long)n * channels, M = (long long)n * hw;
+    hipLaunchKernelGGL(k_bn2d_stats, dim3(channels, nb), dim3(64, 8), 0, s, x, n, channels, hw, part);
+    hipLaunchKernelGGL(k_bn2d_stats_fin, dim3(channels), dim3(64), 0, s, part, nb, M, eps, momentum, save_mean, save_invstd, run_mean, run_var);
+    hipLaunchKernelGGL(k_bn2d_apply, dim3((unsigned)std::min<long long>((rows + 7) / 8, 4096)), dim3(64, 8), 0, s, x, out, rows, channels, hw,
+                       save_mean, save_invstd, gamma, beta, relu);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DBAZ_OK : terr(nullptr, DBAZ_EDEVICE, "bn2d forward: %s", hipGetErrorString(e));
+}
+
+// backward: dout / out / x as in the forward call -> dx [n][C][H*W], dgamma, dbeta [C] (written)
+extern "C" int dbaz_bn2d_backward(const float *dout, const float *out, const float *x, int32_t n, int32_t channels, int32_t hw,
+                                  const float *gamma, const float *save_mean, const float *save_invstd, int32_t relu, float *dx,
+                                  float *dgamma, float *dbeta, void *workspace, void *stream)
+{
+    if (!dout || !out || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace)
+        return terr(nullptr, DBAZ_EINVAL, "null argument");
+    if (n < 1 || channels < 1 || hw < 1) return terr(nullptr, DBAZ_EINVAL, "bn2d: n, channels and H*W must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    double *part = reinterpret_cast<double *>(workspace);
+    double *sums = part + (size_t)channels * BN_NB * 2;
+    const int nb = std::min(BN_NB, (n + 7) / 8);
+    const long long rows = (long long)n * channels, M = (long long)n * hw;
+    hipLaunchKernelGGL(k_bn2d_bwd_sums, dim3(channels, nb), dim3(64, 8), 0, s, dout, out, x, n, channels, hw, save_mean, save_invstd, relu, part);
+    hipLaunchKernelGGL(k_bn2d_bwd_fin, dim3(channels), dim3(64), 0, s, part, nb, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3((unsigned)std::min<long long>((rows + 7) / 8, 4096)), dim3(64, 8), 0, s, dout, out, x, dx, rows, M,
+                       channels, hw, save_mean, save_invstd, gamma, sums, relu);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DBAZ_OK : terr(nullptr, DBAZ_EDEVICE, "bn2d backward: %s", hipGetErrorString(e));
+}

@@ -35,27 +35,32 @@ def training_forward(model, x, hip_tower=None):
         x = model.bn_fc0(F.relu(model.fc0(x)))
         x = model.bn_fc1(F.relu(model.fc1(x)))
         return F.log_softmax(model.policy_fc(x), dim=1), torch.tanh(model.value_fc(x))
-    x = model.bn_input(x)
-    r = model.resnet
-    x = F.relu(r.bn0(r.conv0(x)))
     use_hip = False
     if hip_tower is not False and model.training and x.is_cuda:
         from . import train_tower
         use_hip = train_tower.supported(model, x)
     if hip_tower is True and not use_hip:
         raise RuntimeError("the HIP training tower needs a 64-channel ResNetZero in training mode on a CUDA tensor")
+    r, ph, vh = model.resnet, model.policy_head, model.value_head
     if use_hip:
+        # residual blocks and every BatchNorm2d (+ its ReLU) on csrc/train.hip; convs 3->64 / 1x1 and the FCs on torch
+        bn = train_tower.batch_norm_train
+        x = bn(model.bn_input, x)
+        x = bn(r.bn0, r.conv0(x), relu=True)
         x = train_tower.resblocks_forward(model, x)
+        p = bn(ph.bn0, ph.conv0(x), relu=True)
+        v = bn(vh.bn0, vh.conv0(x), relu=True)
     else:
+        x = model.bn_input(x)
+        x = F.relu(r.bn0(r.conv0(x)))
         for blk in r.resblocks:
             y = F.relu(blk.bn1(blk.conv1(x)))
             y = blk.bn2(blk.conv2(y))
             y += x
             x = F.relu(y)
-    ph, vh = model.policy_head, model.value_head
-    p = F.relu(ph.bn0(ph.conv0(x)))
+        p = F.relu(ph.bn0(ph.conv0(x)))
+        v = F.relu(vh.bn0(vh.conv0(x)))
     p = F.log_softmax(ph.fc(p.view(p.size(0), -1)), dim=1)
-    v = F.relu(vh.bn0(vh.conv0(x)))
     v = F.relu(vh.fc0(v.view(v.size(0), -1)))
     v = torch.tanh(vh.fc1(v))
     return p, v
@@ -66,9 +71,15 @@ class AlphaZeroLoss(tnn.Module):
     returns (loss, (loss_pi, loss_v) as python floats)."""
 
     def forward(self, p, v, pi, z):
+        loss, (loss_pi, loss_v) = self.tensors(p, v, pi, z)
+        return loss, (loss_pi.item(), loss_v.item())
+
+    @staticmethod
+    def tensors(p, v, pi, z):
+        """The same without the two host synchronisations of `.item()`: (loss, (loss_pi, loss_v)) as 0-d tensors."""
         loss_v = (z - v).pow(2).mean()
         loss_pi = -(pi * p).sum(1).mean()
-        return loss_v + loss_pi, (loss_pi.item(), loss_v.item())
+        return loss_v + loss_pi, (loss_pi.detach(), loss_v.detach())
 
 
 class GenerationLrScheduler:
@@ -112,11 +123,11 @@ def load_checkpoint(filename, model, optimizer, to_device):
     return ck["last_batch_idx"]
 
 
-def _accuracy(v, z, threshold=0.5):
+def _accuracy(v, z, threshold=0.5, lazy=False):
     with torch.no_grad():
         correct = z.sign().eq(v.sign())
         correct = correct * (v - z).abs().lt(threshold)
-        return correct.sum().item(), z.size()[0]
+        return (correct.sum() if lazy else correct.sum().item()), z.size()[0]
 
 
 def _batches(dataset, batch_size, shuffle, symmetries, device):
@@ -155,19 +166,34 @@ def train(model, params, train_dataset, val_dataset, writer, generation, device=
     for epoch in range(min(2 * generation, _get(tp, "nb_epochs"))):
         model.train(True)
         tr_loss, tr_batches, tr_ok, tr_tot = 0, 0, 0, 1
+        # The reference reads loss_pi / loss_v / the accuracy count back with .item() in every step (nn.py:136-138,180-184), i.e.
+        # it drains the GPU queue three times per batch.  The values and the order of the writer calls are the same here, but a
+        # step's scalars are fetched only after the NEXT step has been queued, so the device never waits for the host.
+        pending = None
+
+        def flush(pend):
+            nonlocal tr_ok, tr_loss
+            if pend is None:
+                return
+            bi, lpi_t, lv_t, c_t = pend
+            lpi, lv = lpi_t.item(), lv_t.item()
+            tr_ok += int(c_t.item())
+            tr_loss += lpi + lv
+            writer.add_scalars("loss", {"pi/train": lpi, "v/train": lv, "total/train": lpi + lv}, bi)
+
         for boards, pi, z in _batches(train_dataset, _get(tp, "train_batch_size"), True, symmetries, device):
             batch_i += 1
             tr_batches += 1
             p, v = training_forward(model, boards)
-            loss, (loss_pi, loss_v) = criterion(p, v, pi, z)
+            loss, (lpi_t, lv_t) = criterion.tensors(p, v, pi, z)
             loss.backward()
             optimizer.step()
             optimizer.zero_grad()
-            c, t = _accuracy(v, z)
-            tr_ok += c
+            c_t, t = _accuracy(v, z, lazy=True)
             tr_tot += t
-            tr_loss += loss_pi + loss_v
-            writer.add_scalars("loss", {"pi/train": loss_pi, "v/train": loss_v, "total/train": loss_pi + loss_v}, batch_i)
+            flush(pending)
+            pending = (batch_i, lpi_t, lv_t, c_t)
+        flush(pending)
         val_loss, loss_v, loss_pi, val_ok, val_tot = 0.0, 0.0, 0.0, 0, 1
         if val_dataset:
             model.train(False)

@@ -120,3 +120,51 @@ def resblocks_forward(model, x):
             nbt.append(bn.num_batches_tracked)
     torch._foreach_add_(nbt, 1)   # one launch for the 2*blocks counters (BatchNorm2d.forward: num_batches_tracked += 1)
     return _TowerFn.apply(tr, rm, rv, x, *params)
+
+
+# ---- training-mode BatchNorm2d (+ ReLU) of the layers outside the residual blocks (bn_input, bn0, the heads' bn0)
+class _BNFn(torch.autograd.Function):
+    """y = relu?(batch_norm(x)) with batch statistics on csrc/train.hip (dbaz_bn2d_*); running statistics updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, run_mean, run_var, eps, momentum, relu):
+        L = _lib.load()
+        xc = x.detach().contiguous().float()
+        n, ch = xc.shape[0], xc.shape[1]
+        hw = xc.numel() // (n * ch)
+        out = torch.empty_like(xc)
+        mean = torch.empty(ch, dtype=torch.float32, device=xc.device)
+        invstd = torch.empty_like(mean)
+        ws = torch.empty(int(L.dbaz_bn2d_workspace_bytes(ch)) // 8, dtype=torch.float64, device=xc.device)
+        stream = C.c_void_p(torch.cuda.current_stream(xc.device).cuda_stream)
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        rc = L.dbaz_bn2d_forward(xc.data_ptr(), n, ch, hw, w.data_ptr(), b.data_ptr(), run_mean.data_ptr(), run_var.data_ptr(),
+                                 float(eps), float(momentum), int(bool(relu)), out.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                 ws.data_ptr(), stream)
+        if rc != _lib.OK:
+            raise TrainerError((L.dbaz_trainer_last_error(None) or b"dbaz_bn2d_forward failed").decode())
+        ctx.save_for_backward(xc, out, w, mean, invstd)
+        ctx.relu, ctx.ws = bool(relu), ws
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.load()
+        xc, out, w, mean, invstd = ctx.saved_tensors
+        n, ch = xc.shape[0], xc.shape[1]
+        hw = xc.numel() // (n * ch)
+        d = dout.contiguous().float()
+        dx, dw, db = torch.empty_like(xc), torch.empty_like(w), torch.empty_like(w)
+        stream = C.c_void_p(torch.cuda.current_stream(xc.device).cuda_stream)
+        rc = L.dbaz_bn2d_backward(d.data_ptr(), out.data_ptr(), xc.data_ptr(), n, ch, hw, w.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                  int(ctx.relu), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ctx.ws.data_ptr(), stream)
+        if rc != _lib.OK:
+            raise TrainerError((L.dbaz_trainer_last_error(None) or b"dbaz_bn2d_backward failed").decode())
+        return dx, dw, db, None, None, None, None, None
+
+
+def batch_norm_train(bn, x, relu=False):
+    """torch.nn.BatchNorm2d `bn` in training mode on a CUDA tensor (+ ReLU), on the HIP kernels: F.relu(bn(x)) of nn.py:26,82,99
+    and bn_input(x) of nn.py:117."""
+    bn.num_batches_tracked += 1
+    return _BNFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)

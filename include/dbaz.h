@@ -281,6 +281,19 @@ int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, const float *c
                           float *const *g_conv_w, float *const *g_conv_b, float *const *g_bn_w, float *const *g_bn_b,
                           void *stream);
 
+/* ---- training-mode BatchNorm2d (+ ReLU) on NCHW tensors of any channel count: bn_input, bn0 and the heads' bn0
+ * of ResNetZero under model.train(True) (nn.py:19-21,81-83,98-100,114; torch.nn.BatchNorm2d: batch statistics, biased variance,
+ * running-stat update with momentum, gradient through the statistics).  Stateless: all pointers DEVICE memory, `workspace` of
+ * dbaz_bn2d_workspace_bytes(channels) bytes owned by the caller (the backward call may reuse the forward call's), asynchronous
+ * on `stream`; errors: dbaz_trainer_last_error(NULL). */
+int64_t dbaz_bn2d_workspace_bytes(int32_t channels);
+int dbaz_bn2d_forward(const float *x /*[n][C][H*W]*/, int32_t n, int32_t channels, int32_t hw, const float *gamma, const float *beta,
+                      float *run_mean, float *run_var, float eps, float momentum, int32_t relu, float *out, float *save_mean /*[C]*/,
+                      float *save_invstd /*[C]*/, void *workspace, void *stream);
+int dbaz_bn2d_backward(const float *dout, const float *out, const float *x, int32_t n, int32_t channels, int32_t hw, const float *gamma,
+                       const float *save_mean, const float *save_invstd, int32_t relu, float *dx, float *dgamma, float *dbeta,
+                       void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

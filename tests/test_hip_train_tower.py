@@ -240,3 +240,37 @@ def test_full_size_step_batch_4096_20_blocks():
     for k, v in b.state_dict().items():
         if "running" in k:
             assert rel(sth[k], v.double().cpu()) < 1e-5, k
+
+
+@pytest.mark.parametrize("ch,hw,n,relu", [(3, (7, 7), 257, False), (64, (7, 7), 130, True), (16, (4, 4), 33, True), (16, (10, 10), 9, True), (5, (3, 4), 1, False)])
+def test_batch_norm_train_vs_torch_float64(ch, hw, n, relu):
+    """dbaz_bn2d_*: BatchNorm2d in training mode (+ ReLU) on NCHW tensors against torch autograd in float64: output, input
+    gradient, dgamma / dbeta, running statistics, num_batches_tracked."""
+    from dotsboxesaz_amd import train_tower
+    g = torch.Generator().manual_seed(ch * 100 + n)
+    bn = torch.nn.BatchNorm2d(ch)
+    bn.weight.data = torch.rand(ch, generator=g) + 0.5
+    bn.bias.data = torch.randn(ch, generator=g) * 0.3
+    bn.running_mean.data = torch.randn(ch, generator=g) * 0.1
+    bn.running_var.data = torch.rand(ch, generator=g) + 0.5
+    x = torch.randn(n, ch, *hw, generator=g) * 2 + 0.5
+    dout = torch.randn(n, ch, *hw, generator=g)
+    ref = copy.deepcopy(bn).double()
+    ref.train(True)
+    xr = x.double().clone().requires_grad_(True)
+    yr = ref(xr)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dout.double())
+    hip = copy.deepcopy(bn).cuda()
+    hip.train(True)
+    xh = x.cuda().clone().requires_grad_(True)
+    yh = train_tower.batch_norm_train(hip, xh, relu=relu)
+    yh.backward(dout.cuda())
+    torch.cuda.synchronize()
+    if n * hw[0] * hw[1] > 1:
+        assert rel(yh.detach().double().cpu(), yr.detach()) < 2e-6
+        assert rel(xh.grad.double().cpu(), xr.grad) < 2e-5
+        assert rel(hip.weight.grad.double().cpu(), ref.weight.grad) < 2e-5 and rel(hip.bias.grad.double().cpu(), ref.bias.grad) < 2e-5
+        assert rel(hip.running_mean.double().cpu(), ref.running_mean) < 2e-6 and rel(hip.running_var.double().cpu(), ref.running_var) < 2e-6
+    assert int(hip.num_batches_tracked) == 1

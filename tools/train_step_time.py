@@ -36,7 +36,7 @@ def measure(batch=4096, hip=True, steps=10, board=6, channels=64, blocks=20, dev
     sym = SymmetriesGenerator(e)
 
     def epoch(k):
-        done, t_data = 0, 0.0
+        done, t_data, pend = 0, 0.0, None
         while done < k:
             it = iter(ds.loader(batch, True, True, sym))
             while done < k:
@@ -47,10 +47,13 @@ def measure(batch=4096, hip=True, steps=10, board=6, channels=64, blocks=20, dev
                     break
                 t_data += time.perf_counter() - t0
                 p, v = T.training_forward(model, boards, hip_tower=hip)
-                loss, _ = crit(p, v, pi, z)
+                loss, parts = crit.tensors(p, v, pi, z)      # as train.train(): the scalars are read one step late
                 loss.backward()
                 opt.step()
                 opt.zero_grad()
+                if pend is not None:
+                    pend[0].item(), pend[1].item()
+                pend = parts
                 done += 1
         torch.cuda.synchronize()
         return t_data
