@@ -274,3 +274,21 @@ def test_batch_norm_train_vs_torch_float64(ch, hw, n, relu):
         assert rel(hip.weight.grad.double().cpu(), ref.weight.grad) < 2e-5 and rel(hip.bias.grad.double().cpu(), ref.bias.grad) < 2e-5
         assert rel(hip.running_mean.double().cpu(), ref.running_mean) < 2e-6 and rel(hip.running_var.double().cpu(), ref.running_var) < 2e-6
     assert int(hip.num_batches_tracked) == 1
+
+
+def test_exact_f32_weight_gradient_path(monkeypatch):
+    """DBAZ_TRAIN_WGRAD_F32=1 selects k_wgrad (v_mfma_f32_16x16x4_f32, exact products) instead of k_wgrad_h3: same gradients."""
+    from dotsboxesaz_amd import train_tower
+    blocks = make_blocks(1, 5)
+    g = torch.Generator().manual_seed(9)
+    x = torch.relu(torch.randn(21, 64, 7, 7, generator=g))
+    gout = torch.randn(21, 64, 7, 7, generator=g) * 1e-2
+    _, _, gr64, _ = run_torch(blocks, x, gout, torch.float64)
+    train_tower._trainers.clear()
+    _, _, gr_h3, _, _ = run_hip(blocks, x, gout)
+    monkeypatch.setenv("DBAZ_TRAIN_WGRAD_F32", "1")
+    train_tower._trainers.clear()
+    _, _, gr_f32, _, _ = run_hip(blocks, x, gout)
+    train_tower._trainers.clear()
+    for k in ("0.conv1.weight", "0.conv2.weight"):
+        assert rel(gr_f32[k], gr64[k]) < 2e-5 and rel(gr_h3[k], gr64[k]) < 2e-5 and rel(gr_f32[k], gr_h3[k]) < 2e-5
