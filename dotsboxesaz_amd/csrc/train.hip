@@ -433,10 +433,15 @@ __global__ void __launch_bounds__(TT) k_bn_stats(const f32x4 *__restrict__ y4, l
 {
     double s[2][4] = {};
     const int cq = threadIdx.x & 15;
-    for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += (long long)gridDim.x * 32) {
-        const f32x4 v = y4[r * 16 + cq];
+    const long long rs = (long long)gridDim.x * 32;
+    for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += 4 * rs) {
+        f32x4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) { const double d = v[e]; s[0][e] += d; s[1][e] += d * d; }
+        for (int u = 0; u < 4; u++) v[u] = r + u * rs < M ? y4[(r + u * rs) * 16 + cq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const double d = v[u][e]; s[0][e] += d; s[1][e] += d * d; }
     }
     block_colsum_store<2>(s, part);
 }
@@ -472,12 +477,25 @@ __global__ void __launch_bounds__(256) k_bn_apply(const f32x4 *__restrict__ y4, 
     const f32x4 sc = *reinterpret_cast<const f32x4 *>(invstd + cq * 4) * *reinterpret_cast<const f32x4 *>(gamma + cq * 4);
     const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + cq * 4);
     float mx = 0.0f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        f32x4 v = (y4[i] - mu) * sc + be;
-        if (res4) v += res4[i];
+    // four quads per thread and pass, all loads issued before the first use (1-2 loads in flight per thread left the kernel at
+    // 4.4 TB/s)
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+        f32x4 y[4], r[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) { v[e] = fmaxf(v[e], 0.0f); mx = fmaxf(mx, v[e]); }
-        out4[i] = v;
+        for (int u = 0; u < 4; u++) {
+            const long long i = i0 + u * stride;
+            y[u] = i < n4 ? y4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            r[u] = (res4 && i < n4) ? res4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long i = i0 + u * stride;
+            f32x4 v = (y[u] - mu) * sc + be + r[u];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] = fmaxf(v[e], 0.0f); mx = fmaxf(mx, v[e]); }
+            if (i < n4) out4[i] = v;
+        }
     }
     block_atomic_max(mx, amax); // one atomic per workgroup (one per wave of a 4 096-workgroup grid serialised for 160 us)
 }
