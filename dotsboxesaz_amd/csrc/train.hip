@@ -60,6 +60,7 @@ struct dbaz_trainer {
     double *part = nullptr;      // [RED_BLOCKS][4][C] partial column sums
     double *sums = nullptr;      // [4][C]
     float *wg_part = nullptr;    // [cus][9][C][C]
+    unsigned long long *relu_mask = nullptr; // [L][maxN*HW]: sign bits of A[l+1] (64 channels per row)
 };
 
 static std::string g_train_error;
@@ -468,9 +469,17 @@ __global__ void __launch_bounds__(TT) k_bn_stats_fin(const double *part, int npa
 }
 
 // A_out = relu(gamma * (y - mean) * invstd + beta (+ res)); tracks max(A_out)
+// one bit per element: (row, channel) is set where the layer's output is > 0 -- what the backward pass needs of A (the ReLU mask)
+// at 8 bytes per row instead of 256; bit 16 e + cq of mask[row] belongs to element e of channel quad cq (four 16-lane ballots)
+__device__ __forceinline__ unsigned quad_mask(unsigned long long m, int cq)
+{
+    const unsigned lo = (unsigned)(m >> cq), hi = (unsigned)(m >> (32 + cq));
+    return (lo & 1u) | ((lo >> 15) & 2u) | ((hi & 1u) << 2) | ((hi >> 13) & 8u);
+}
+
 __global__ void __launch_bounds__(256) k_bn_apply(const f32x4 *__restrict__ y4, const f32x4 *__restrict__ res4, f32x4 *__restrict__ out4,
                                                   long long n4, const float *mean, const float *invstd, const float *gamma,
-                                                  const float *beta, unsigned *amax)
+                                                  const float *beta, unsigned *amax, unsigned long long *__restrict__ mask)
 {
     const int cq = threadIdx.x & 15; // (blockDim and the grid stride are multiples of 16)
     const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cq * 4);
@@ -492,9 +501,16 @@ __global__ void __launch_bounds__(256) k_bn_apply(const f32x4 *__restrict__ y4, 
         for (int u = 0; u < 4; u++) {
             const long long i = i0 + u * stride;
             f32x4 v = (y[u] - mu) * sc + be + r[u];
+            unsigned long long bits = 0;
+            const int sh = threadIdx.x & 48; // first lane of this row's 16 lanes within the wave
 #pragma unroll
-            for (int e = 0; e < 4; e++) { v[e] = fmaxf(v[e], 0.0f); mx = fmaxf(mx, v[e]); }
+            for (int e = 0; e < 4; e++) {
+                v[e] = fmaxf(v[e], 0.0f);
+                mx = fmaxf(mx, v[e]);
+                bits |= ((__ballot(v[e] > 0.0f && i < n4) >> sh) & 0xffffull) << (16 * e);
+            }
             if (i < n4) out4[i] = v;
+            if (cq == 0 && i < n4) mask[i >> 4] = bits;
         }
     }
     block_atomic_max(mx, amax); // one atomic per workgroup (one per wave of a 4 096-workgroup grid serialised for 160 us)
@@ -502,7 +518,7 @@ __global__ void __launch_bounds__(256) k_bn_apply(const f32x4 *__restrict__ y4, 
 
 // backward, pass 1: g = dA * (A_out > 0); partials of sum(g) and sum(g * yhat); the _fin kernel turns them into dbeta, dgamma
 // and `sums` for pass 2 and clears the max|dY| word pass 2 accumulates into
-__global__ void __launch_bounds__(TT) k_bn_bwd_sums(const f32x4 *__restrict__ dA4, const f32x4 *__restrict__ aout4, const f32x4 *__restrict__ y4,
+__global__ void __launch_bounds__(TT) k_bn_bwd_sums(const f32x4 *__restrict__ dA4, const unsigned long long *__restrict__ mask, const f32x4 *__restrict__ y4,
                                                     long long M, const float *mean, const float *invstd, double *part)
 {
     double s[2][4] = {};
@@ -510,10 +526,11 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_sums(const f32x4 *__restrict__ dA
     const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cq * 4);
     const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + cq * 4);
     for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += (long long)gridDim.x * 32) {
-        const f32x4 d = dA4[r * 16 + cq], ao = aout4[r * 16 + cq], y = y4[r * 16 + cq];
+        const f32x4 d = dA4[r * 16 + cq], y = y4[r * 16 + cq];
+        const unsigned m = quad_mask(mask[r], cq);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const float g = ao[e] > 0.0f ? d[e] : 0.0f;
+            const float g = ((m >> e) & 1u) ? d[e] : 0.0f;
             const float yh = (y[e] - mu[e]) * is[e];
             s[0][e] += (double)g;
             s[1][e] += (double)g * (double)yh;
@@ -538,7 +555,7 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_sums_fin(const double *part, int 
 
 // backward, pass 2: dY = gamma * invstd * (g - sum(g)/M - yhat * sum(g*yhat)/M); keeps g (skip path of a block's end);
 // tracks max|dY|; partials of sum(dY) (the conv bias gradient: k_dbias_fin)
-__global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ dA4, const f32x4 *__restrict__ aout4, const f32x4 *__restrict__ y4,
+__global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ dA4, const unsigned long long *__restrict__ mask, const f32x4 *__restrict__ y4,
                                                      long long M, const float *mean, const float *invstd, const float *gamma,
                                                      const double *sums, f32x4 *__restrict__ dY4, f32x4 *__restrict__ g4,
                                                      unsigned *amax, double *part)
@@ -556,11 +573,12 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ d
     }
     float mx = 0.0f;
     for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += (long long)gridDim.x * 32) {
-        const f32x4 d = dA4[r * 16 + cq], ao = aout4[r * 16 + cq], y = y4[r * 16 + cq];
+        const f32x4 d = dA4[r * 16 + cq], y = y4[r * 16 + cq];
+        const unsigned m = quad_mask(mask[r], cq);
         f32x4 g, o;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            g[e] = ao[e] > 0.0f ? d[e] : 0.0f;
+            g[e] = ((m >> e) & 1u) ? d[e] : 0.0f;
             const float yh = (y[e] - mu[e]) * is[e];
             o[e] = ga[e] * is[e] * (g[e] - mg[e] - yh * mgy[e]);
             mx = fmaxf(mx, fabsf(o[e]));
@@ -925,7 +943,7 @@ extern "C" void dbaz_trainer_destroy(dbaz_trainer *t)
 {
     if (!t) return;
     (void)hipSetDevice(t->dev);
-    void *ptrs[] = {t->A, t->Y, t->G, t->dA[0], t->dA[1], t->dY, t->wpk, t->wsc, t->amax, t->mean, t->invstd, t->part, t->sums, t->wg_part};
+    void *ptrs[] = {t->A, t->Y, t->G, t->dA[0], t->dA[1], t->dY, t->wpk, t->wsc, t->amax, t->mean, t->invstd, t->part, t->sums, t->wg_part, t->relu_mask};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -977,6 +995,7 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     alloc((void **)&t->part, (size_t)RED_BLOCKS * 4 * TC * 8);
     alloc((void **)&t->sums, (size_t)4 * TC * 8);
     alloc((void **)&t->wg_part, (size_t)t->cus * 9 * TC * TC * 4);
+    alloc((void **)&t->relu_mask, (size_t)t->L * t->maxN * t->HW * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
     t->occ2 = getenv("DBAZ_TRAIN_OCC1") ? 0 : 1;
@@ -1033,7 +1052,7 @@ extern "C" int dbaz_trainer_forward(dbaz_trainer *t, int32_t n, const float *x, 
         hipLaunchKernelGGL(k_bn_apply, dim3(ab), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l),
                            (l & 1) ? reinterpret_cast<const f32x4 *>(t->A + ae * (l - 1)) : nullptr,
                            reinterpret_cast<f32x4 *>(t->A + ae * (l + 1)), n4, t->mean + l * TC, t->invstd + l * TC, bn_w[l], bn_b[l],
-                           t->amax + l + 1);
+                           t->amax + l + 1, t->relu_mask + (size_t)l * t->maxN * HW);
     }
     hipLaunchKernelGGL(k_rows_to_nchw, dim3(n), dim3(256), (size_t)HW * (TC + 1) * 4, s, t->A + ae * L, out, HW);
     HIPCHK(t, hipGetLastError());
@@ -1067,7 +1086,7 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
     hipLaunchKernelGGL(k_nchw_to_rows, dim3(n), dim3(256), (size_t)TC * (HW + 1) * 4, s, grad_out, t->dA[cur], HW, (unsigned *)nullptr);
     for (int l = L - 1; l >= 0; l--) {
         const f32x4 *dA4 = reinterpret_cast<const f32x4 *>(t->dA[cur]);
-        const f32x4 *ao4 = reinterpret_cast<const f32x4 *>(t->A + ae * (l + 1));
+        const unsigned long long *ao4 = t->relu_mask + (size_t)l * t->maxN * HW; // sign bits of A[l + 1]
         const f32x4 *y4 = reinterpret_cast<const f32x4 *>(t->Y + ae * l);
         hipLaunchKernelGGL(k_bn_bwd_sums, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, t->part);
         hipLaunchKernelGGL(k_bn_bwd_sums_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, t->sums, g_bn_b[l], g_bn_w[l], dymax);
