@@ -48,7 +48,6 @@ struct dbaz_trainer {
     float eps = 1e-5f, momentum = 0.1f;
     size_t conv_lds = 0, wgrad_lds = 0;
     bool have_fwd = false;
-    int occ2 = 1; // k_conv_t2 (two workgroups per CU)
     int wgrad_h3 = 1, Swh = 1; // k_wgrad_h3 (f16x3) and its samples per chunk; 0: the exact-f32 k_wgrad
     size_t wgrad_h3_lds = 0;
     std::string err;
@@ -191,7 +190,7 @@ __global__ void __launch_bounds__(TT) k_pack_w(PackArgs pa, _Float16 *__restrict
 // conv3x3 64 -> 64 over NHWC rows, f16x3 on v_mfma_f32_16x16x32_f16 with two cout tiles per wave (the tiling of
 // nn.hip's conv_lds_h3_c2): a workgroup stages the S samples' rows as (hi, lo) halves in an LDS image of (C+8)-dword rows,
 // wave w owns couts [32 (w & 1), +32) and position tiles [4 (w >> 1), +4); out-of-image taps read a zero region at the
-// lane's own bank slot.  out = acc * 2^-(sx+sw) (+ bias) (+ add).
+// lane's own bank slot.  out = acc * 2^-(sx+sw) (+ bias) (+ add).  128 registers: two workgroups per CU.
 // ------------------------------------------------------------------------------------
 struct ConvArgs {
     const float *in;          // [n*HW][C]
@@ -204,8 +203,7 @@ struct ConvArgs {
     int n, S, H, W;
 };
 
-template <int OCC>
-__device__ __forceinline__ void conv_t_body(const ConvArgs &a)
+__global__ void __launch_bounds__(TT, 4) k_conv_t(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int C = TC, S4 = (C + 8) / 4, KS = C / 32, LO = C / 8, N = 9 * KS, NTT = 4;
@@ -221,7 +219,7 @@ __device__ __forceinline__ void conv_t_body(const ConvArgs &a)
     const int ct0 = (wave & 1) * 2;
     // weight fragments (L2 -> registers) run RD - 1 steps ahead in an RD-deep ring; the first RD - 1 steps are fetched before
     // the staging so that their latency hides behind it
-    constexpr int RD = OCC == 2 ? 2 : 3;
+    constexpr int RD = 2;
     const f32x4 *wb0 = wpk + (size_t)ct0 * N * 2 * 64 + lane;
     const f32x4 *wb1 = wb0 + (size_t)N * 2 * 64;
     u128h a_h[2][RD], a_l[2][RD];
@@ -362,11 +360,6 @@ __device__ __forceinline__ void conv_t_body(const ConvArgs &a)
         }
     }
 }
-
-// two instantiations: 1 workgroup per CU (144 registers) or 2 (128 registers, a few spills): the second overlaps one
-// workgroup's staging and stores with the other's MFMA loop
-__global__ void __launch_bounds__(TT, 2) k_conv_t(ConvArgs a) { conv_t_body<1>(a); }
-__global__ void __launch_bounds__(TT, 4) k_conv_t2(ConvArgs a) { conv_t_body<2>(a); }
 
 // ------------------------------------------------------------------------------------
 // column sums over the rows of [M][C] tensors, f64: the workgroup's 512 threads = 32 row lanes x 16 channel quads write one
@@ -997,8 +990,6 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     alloc((void **)&t->wg_part, (size_t)t->cus * 9 * TC * TC * 4);
     alloc((void **)&t->relu_mask, (size_t)t->L * t->maxN * t->HW * 8);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
-    t->occ2 = getenv("DBAZ_TRAIN_OCC1") ? 0 : 1;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad_h3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_h3_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad_h3<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_h3_lds);
@@ -1044,8 +1035,7 @@ extern "C" int dbaz_trainer_forward(dbaz_trainer *t, int32_t n, const float *x, 
         ca.wpk = t->wpk + (size_t)l * TC * TC * 9 * 2; ca.wsc = t->wsc + l;
         ca.bias = conv_b[l]; ca.add = nullptr; ca.out = t->Y + ae * l;
         ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
-        if (t->occ2) hipLaunchKernelGGL(k_conv_t2, dim3(grid), dim3(TT), t->conv_lds, s, ca);
-        else hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         hipLaunchKernelGGL(k_bn_stats, dim3(rb), dim3(TT), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l), M, t->part);
         hipLaunchKernelGGL(k_bn_stats_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, M, t->eps, t->momentum, t->mean + l * TC,
                            t->invstd + l * TC, run_mean ? run_mean[l] : nullptr, run_var ? run_var[l] : nullptr);
@@ -1109,8 +1099,7 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
         ca.bias = nullptr; ca.out = t->dA[1 - cur];
         ca.add = (l & 1) ? nullptr : t->G; // the input of a block's first conv is also the block's skip input: + g of its end
         ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
-        if (t->occ2) hipLaunchKernelGGL(k_conv_t2, dim3(grid), dim3(TT), t->conv_lds, s, ca);
-        else hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
+        hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         cur = 1 - cur;
     }
     hipLaunchKernelGGL(k_rows_to_nchw, dim3(n), dim3(256), (size_t)HW * (TC + 1) * 4, s, t->dA[cur], grad_x, HW);
