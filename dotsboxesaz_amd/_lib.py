@@ -48,7 +48,7 @@ class Counters(C.Structure):
         ("sum_path", C.c_int64), ("games_finished", C.c_int64), ("rows_ready", C.c_int64), ("moves_played", C.c_int64),
         ("pool_high_water", C.c_int64), ("active_slots", C.c_int32), ("error_slots", C.c_int32), ("blocked_slots", C.c_int32), ("f32_fallback_evals", C.c_int32),
         ("ms_total", C.c_double), ("ms_tree", C.c_double), ("ms_nn", C.c_double), ("nn_launches", C.c_int64),
-        ("ms_nn_tower", C.c_double), ("cache_hits", C.c_int64),
+        ("ms_nn_tower", C.c_double), ("cache_hits", C.c_int64), ("pool_resets", C.c_int64),
     ]
 
 

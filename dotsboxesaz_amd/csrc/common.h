@@ -77,11 +77,12 @@ struct Slot {
     int32_t quick_until;     // benchmark population: plies of the slot's FIRST game that are searched with SearchCfg.quick_reads
     int32_t wave_sims;       // K > 1 search: simulations selected in the current wave, waiting for expand/backup
     int32_t first_wave;      // K > 1 search: the first wave of a UCT_search call is min(K, A) wide (mcts.py:228-229)
+    int32_t pool_resets;     // self-play driver: moves whose kept subtree would not have left room for the next search (fresh root instead)
 };
 
 // device-side reduction of the Slot array (dbaz_get_counters / dbaz_run poll this instead of copying every Slot)
 struct SlotSummary {
-    unsigned long long n_search, n_eval, n_hit, n_term, sum_path;
+    unsigned long long n_search, n_eval, n_hit, n_term, sum_path, n_reset;
     int32_t active, error, blocked, pool_high;
     int32_t first_error_slot, first_error_code; // lowest slot index in PH_ERROR (or 0x7fffffff) and its code
 };

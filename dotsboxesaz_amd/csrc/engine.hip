@@ -1014,6 +1014,7 @@ static int slot_summary(dbaz_engine *e, dbaz_counters *c, SlotSummary *raw = nul
     c->expansions = (int64_t)s.n_search;
     c->nn_evals = (int64_t)s.n_eval;
     c->cache_hits = (int64_t)s.n_hit;
+    c->pool_resets = (int64_t)s.n_reset;
     c->terminal_leaves = (int64_t)s.n_term;
     c->sum_path = (int64_t)s.sum_path;
     c->active_slots = s.active;

@@ -1254,8 +1254,13 @@ __device__ __forceinline__ void pool_reset(Slot *S)
 }
 
 // re-root slot on `move`; returns 0 or an error code.  wave-uniform.
+// need_free > 0 (the self-play driver): the kept subtree holds at most `carried` nodes (every node below the chosen child was
+// created by a distinct simulation through it); if `carried + need_free` exceeds the pool, the next search could run out of nodes
+// half-way.  The reference's trees are unbounded Python objects; here such a move starts from a fresh root instead (as with
+// reuse_tree = 0, counted in Slot::pool_resets) -- a trained network that puts nearly all visits on one move for many plies in a
+// row (a chain) keeps nearly everything, move after move.  need_free = 0 (dbaz_advance): no check, exhaustion stays an error.
 __device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32_t *pool, int move,
-                      int reuse, int lane)
+                      int reuse, int lane, int need_free = 0)
 {
     const int root = S->root;
     NodeMeta rm = load_meta(pool, g, root);
@@ -1278,6 +1283,10 @@ __device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32
         carried = 0;
     }
     __syncthreads();
+    if (reuse && child >= 0 && need_free > 0 && carried + need_free > g.cap) {
+        reuse = 0;
+        if (lane == 0) S->pool_resets++;
+    }
     if (reuse && child >= 0) {
         const int tail = S->pend_tail;
         if (lane == 0) {
@@ -1389,6 +1398,7 @@ __global__ void __launch_bounds__(WAVE) k_set_positions(Geo g, SearchCfg cfg, Tr
         S->phase = err ? PH_ERROR : PH_IDLE;
         S->n_search = S->sum_path = S->n_eval = S->n_term = S->n_hit = 0;
         S->pool_high = 1;
+        S->pool_resets = 0;
     }
 }
 
@@ -1503,6 +1513,7 @@ __global__ void __launch_bounds__(WAVE) k_selfplay_start(Geo g, SearchCfg cfg, T
         S->error = 0;
         S->n_search = S->sum_path = S->n_eval = S->n_term = S->n_hit = 0;
         S->pool_high = 1;
+        S->pool_resets = 0;
     }
     // deterministic initial assignment: slot i takes game first+i (the dispenser starts behind them)
     long long gidx = B.first_game + slot;
@@ -1611,7 +1622,7 @@ __device__ void advance_one(const Geo &g, const SearchCfg &cfg, const TreeBufs &
     }
     __syncthreads();
     // ---- init_mcts_tree ----
-    int err = reroot(g, B, slot, S, pool, mv, cfg.reuse_tree, lane);
+    int err = reroot(g, B, slot, S, pool, mv, cfg.reuse_tree, lane, cfg.mcts_num_read + 2);
     if (err) {
         if (lane == 0) { S->error = err; S->phase = PH_ERROR; }
         return;
@@ -1734,12 +1745,12 @@ __global__ void k_get_leaves(Geo g, TreeBufs B, int n_slots, int16_t *leaf_x, ui
 // Slot array -> SlotSummary (out must be zeroed except first_error_slot = 0x7fffffff)
 __global__ void __launch_bounds__(256) k_slot_summary(TreeBufs B, int n_slots, SlotSummary *out)
 {
-    unsigned long long ns = 0, ne = 0, nh = 0, nt = 0, sp = 0;
+    unsigned long long ns = 0, ne = 0, nh = 0, nt = 0, sp = 0, nr = 0;
     int active = 0, error = 0, blocked = 0, high = 0, ferr = 0x7fffffff;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x) {
         const Slot &S = B.slots[i];
         ns += (unsigned long long)S.n_search; ne += (unsigned long long)S.n_eval; nh += (unsigned long long)S.n_hit;
-        nt += (unsigned long long)S.n_term; sp += (unsigned long long)S.sum_path;
+        nt += (unsigned long long)S.n_term; sp += (unsigned long long)S.sum_path; nr += (unsigned long long)S.pool_resets;
         const int ph = S.phase;
         if (ph == PH_ERROR) { error++; ferr = min(ferr, i); }
         else if (S.game_idx >= 0 && ph != PH_IDLE) active++;
@@ -1748,12 +1759,13 @@ __global__ void __launch_bounds__(256) k_slot_summary(TreeBufs B, int n_slots, S
     }
     for (int o = 32; o > 0; o >>= 1) {
         ns += __shfl_xor(ns, o); ne += __shfl_xor(ne, o); nh += __shfl_xor(nh, o); nt += __shfl_xor(nt, o); sp += __shfl_xor(sp, o);
+        nr += __shfl_xor(nr, o);
         active += __shfl_xor(active, o); error += __shfl_xor(error, o); blocked += __shfl_xor(blocked, o);
         high = max(high, __shfl_xor(high, o)); ferr = min(ferr, __shfl_xor(ferr, o));
     }
     if ((threadIdx.x & (WAVE - 1)) == 0) {
         atomicAdd(&out->n_search, ns); atomicAdd(&out->n_eval, ne); atomicAdd(&out->n_hit, nh); atomicAdd(&out->n_term, nt);
-        atomicAdd(&out->sum_path, sp);
+        atomicAdd(&out->sum_path, sp); atomicAdd(&out->n_reset, nr);
         atomicAdd(&out->active, active); atomicAdd(&out->error, error); atomicAdd(&out->blocked, blocked);
         atomicMax(&out->pool_high, high);
         if (ferr != 0x7fffffff) atomicMin(&out->first_error_slot, ferr);

@@ -163,8 +163,20 @@ class NeuralNetWrapper:
         HBM when the datasets are train_data.ReplayDataset objects.  The trained weights are pushed
         back into the HIP engine so that the next self-play generation uses them."""
         from . import train as T
+        import torch
+
+        def eval_forward(model):
+            # validation passes on the HIP inference engine: the epoch's weights go in once, the batches through predict_sync
+            self.engine.load_state_dict(model.state_dict(), model.kind, **model.shape)
+
+            def fwd(boards):
+                p, v = self.engine.predict(boards.detach().cpu().numpy())
+                lp = torch.log(torch.from_numpy(p).clamp_min(1e-38)).to(boards.device)
+                return lp, torch.from_numpy(v).to(boards.device)
+            return fwd
+
         last = T.train(self.model, self.params, train_dataset, val_dataset, writer, generation,
-                       device="cuda:%d" % self.engine.cfg.device)
+                       device="cuda:%d" % self.engine.cfg.device, eval_forward=eval_forward)
         self.model.to("cpu")
         self.set_model(self.model)
         return last

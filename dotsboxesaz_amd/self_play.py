@@ -189,6 +189,17 @@ def unpack_rows(packed, F, A):
     return {k: v[order] for k, v in out.items()}
 
 
+def _warn_pool_resets(engine, counters):
+    """The reference's search trees are unbounded; a slot's node pool is not.  When the subtree kept by tree reuse would not leave
+    room for the next search, the engine starts that move from a fresh root (dbaz_counters.pool_resets) -- say so once per run."""
+    n = int(counters.get("pool_resets", 0))
+    if n:
+        import warnings
+        warnings.warn("%d moves (of %d) were searched from a fresh root because the reused subtree did not leave mcts_num_read + 2 nodes "
+                      "of the slot's pool free: raise nodes_per_slot (now %d) to keep the reference's tree reuse on every move"
+                      % (n, int(counters.get("moves_played", 0)), int(engine.cfg.nodes_per_slot) or 10 * (int(engine.cfg.mcts_num_read) + 2)))
+
+
 def collect_rows_device(engine, count, first):
     """Play games first .. first+count-1 and return their packed rows as ONE uint8 CUDA tensor
     [n, row_bytes]; the rows never visit the host.  Whenever the device row buffer fills (the
@@ -208,6 +219,7 @@ def collect_rows_device(engine, count, first):
             engine.replay_rows_clear()
             if c["active_slots"] == 0:
                 break
+        _warn_pool_resets(engine, c)
     if chunks:
         return torch.cat(chunks, dim=0)
     return torch.zeros((0, engine.row_bytes), dtype=torch.uint8, device=dev)

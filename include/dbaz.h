@@ -102,6 +102,9 @@ typedef struct {
     int64_t nn_launches;    /* conv-tower launches inside the timed region */
     double ms_nn_tower;     /* summed duration of the dominant conv kernel */
     int64_t cache_hits;     /* leaves whose (p, v) came from an already evaluated twin position of the same tree */
+    int64_t pool_resets;    /* self-play driver: moves that started from a fresh root because the subtree kept by tree reuse would
+                             * not have left mcts_num_read + 2 nodes of the slot's pool free (the reference's trees are unbounded;
+                             * 0 unless a network concentrates its visits for many plies in a row: raise nodes_per_slot) */
 } dbaz_counters;
 
 const char *dbaz_last_error(const dbaz_engine *e); /* e may be NULL: error of the last dbaz_create */

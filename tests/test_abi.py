@@ -33,7 +33,7 @@ def test_library_exports_every_symbol():
 def test_struct_sizes_match_header():
     # dbaz_config / dbaz_counters layouts as the C compiler sees them
     assert ctypes.sizeof(_lib.Config) == 200
-    assert ctypes.sizeof(_lib.Counters) == 136
+    assert ctypes.sizeof(_lib.Counters) == 144
 
 
 def test_create_without_gpu_fails_loudly():

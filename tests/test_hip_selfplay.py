@@ -363,3 +363,47 @@ def test_rows_do_not_depend_on_slot_scheduling():
     assert len(a["z"]) == len(b["z"])
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_tight_node_pool_falls_back_to_a_fresh_root_bit_exactly():
+    """The reference's trees are unbounded Python objects; a slot's node pool is not.  When the subtree kept by tree reuse
+    (<= the chosen child's visit count nodes) plus the next search (mcts_num_read + 2) would not fit nodes_per_slot, the
+    driver starts that move from a fresh root -- exactly init_mcts_tree(..., reuse_tree=False) (mcts.py:176-179) -- and counts
+    it.  The oracle replays every game move by move with that rule restated here: visit vectors, tree_size and the
+    expansion count are bit-identical; with the default pool size the same games never need it."""
+    import math
+    from dotsboxesaz_amd.engine import Engine
+    rows, cols, sims, cap, n_games = 3, 3, 40, 100, 60
+    e = Engine(rows, cols, 16, mcts_num_read=sims, noise=(0.0, 0.0), evaluator="formula", seed=77, nodes_per_slot=cap)
+    e.selfplay_start(n_games, 0)
+    e.run()
+    cnt = e.counters()
+    assert cnt["games_finished"] == n_games and cnt["error_slots"] == 0 and cnt["pool_resets"] > 0
+    assert cnt["pool_high_water"] <= cap
+    got = e.fetch_samples()
+    e.close()
+    d = O.dims(rows, cols)
+    ev = O.Evaluator(0)
+    resets = searches = 0
+    for gi in range(n_games):
+        r = np.nonzero(got["game_idx"] == gi)[0]
+        t = O.Tree(d, O.new_state(d))
+        for i in r:
+            n_valid = int(O.valid_moves(d, t.state).sum())
+            reads = min(4 * math.factorial(n_valid), sims) if n_valid <= 5 else sims
+            searches += reads + (0 if t.is_expanded else 1)
+            t.search(reads, ev)
+            _, _, nv, _ = t.root_arrays()
+            assert np.array_equal(nv, got["visits"][i]), (gi, i)
+            assert t.stats()[1] == got["tree_size"][i]
+            mv = int(got["played"][i])
+            keep = int(nv[mv]) + sims + 2 <= cap        # the rule of csrc/tree.hip reroot(): kept nodes <= visits of the child
+            resets += 0 if keep else 1
+            t.advance(mv, reuse_tree=keep)
+    assert resets == cnt["pool_resets"] and searches == cnt["expansions"]
+    # the default pool (10 * (reads + 2) nodes) plays the same seeds without a single reset
+    e = Engine(rows, cols, 16, mcts_num_read=sims, noise=(0.0, 0.0), evaluator="formula", seed=77)
+    e.selfplay_start(n_games, 0)
+    e.run()
+    assert e.counters()["pool_resets"] == 0
+    e.close()
