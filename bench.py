@@ -227,7 +227,7 @@ def play_complete_games(args, n_games, slots, rank, local_rank, torch, budget_s=
            "mean_path_len": c["sum_path"] / max(1, c["expansions"]),
            "terminal_leaf_fraction": c["terminal_leaves"] / max(1, c["expansions"]),
            "cache_hit_fraction": c["cache_hits"] / max(1, c["expansions"]),
-           "pool_high_water": c["pool_high_water"], "steps": c["steps"]}
+           "pool_high_water": c["pool_high_water"], "pool_resets": c["pool_resets"], "steps": c["steps"]}
     eng.close()
     return out
 
@@ -266,7 +266,7 @@ def single_tree_bench(args, local_rank, torch):
         reads = int(r["root_nv"][0]) - 1
         res[str(K)] = {"reads": reads, "seconds": dt, "reads_per_sec": reads / dt, "nn_evals": c["nn_evals"],
                        "shared_pending_leaves": c["cache_hits"], "mean_path_len": c["sum_path"] / max(1, c["expansions"]),
-                       "most_visited_share": float(r["visits"][0].max()) / max(1, reads), "pool_high_water": c["pool_high_water"]}
+                       "most_visited_share": float(r["visits"][0].max()) / max(1, reads), "pool_high_water": c["pool_high_water"], "pool_resets": c["pool_resets"]}
         eng.close()
     out = {"metric": "single_tree_reads_per_sec", "value": res[str(args.pending)]["reads_per_sec"], "unit": "reads/s", "n_gpus": 1,
            "higher_is_better": True, "data": "synthetic", "by_pending": res,

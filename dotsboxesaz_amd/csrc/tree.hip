@@ -1254,9 +1254,9 @@ __device__ __forceinline__ void pool_reset(Slot *S)
 }
 
 // re-root slot on `move`; returns 0 or an error code.  wave-uniform.
-// need_free > 0 (the self-play driver): the kept subtree holds at most `carried` nodes (every node below the chosen child was
-// created by a distinct simulation through it); if `carried + need_free` exceeds the pool, the next search could run out of nodes
-// half-way.  The reference's trees are unbounded Python objects; here such a move starts from a fresh root instead (as with
+// need_free > 0 (the self-play driver): the kept subtree holds at most min(`carried`, nodes of the whole tree - 1) nodes (every
+// node below the chosen child was created by a distinct simulation through it); if that plus need_free exceeds the pool, the next
+// search could run out of nodes half-way.  The reference's trees are unbounded Python objects; here such a move starts from a fresh root instead (as with
 // reuse_tree = 0, counted in Slot::pool_resets) -- a trained network that puts nearly all visits on one move for many plies in a
 // row (a chain) keeps nearly everything, move after move.  need_free = 0 (dbaz_advance): no check, exhaustion stays an error.
 __device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32_t *pool, int move,
@@ -1284,8 +1284,22 @@ __device__ int reroot(const Geo &g, const TreeBufs &B, int slot, Slot *S, uint32
     }
     __syncthreads();
     if (reuse && child >= 0 && need_free > 0 && carried + need_free > g.cap) {
-        reuse = 0;
-        if (lane == 0) S->pool_resets++;
+        // visits over-count nodes (a revisit of a terminal leaf creates none: end games carry thousands of visits on a few
+        // hundred nodes), so take the exact count before giving the subtree up: with the collector drained, the nodes in use
+        // are those of the current tree (root, kept child and siblings)
+        PoolState q = pool_load(S);
+        while (q.tail > q.head) {
+            pool_collect<4>(g, B, slot, pool, q, lane);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the next batch reads ring entries this one pushed
+        }
+        if (lane == 0) pool_store(q, S);
+        const int live = q.n_nodes - q.n_free - 1;
+        if ((carried < live ? carried : live) + need_free > g.cap) {
+            reuse = 0;
+            if (lane == 0) S->pool_resets++;
+        }
+        __syncthreads();
     }
     if (reuse && child >= 0) {
         const int tail = S->pend_tail;

@@ -283,6 +283,12 @@ class Tree:
         lib().ob_tree_root_slot(self.ptr, C.byref(tv), C.byref(nv))
         return np.float32(tv.value), nv.value
 
+    def live_nodes(self):
+        """nodes of the current tree, root included"""
+        f = lib().ob_tree_live_nodes
+        f.restype, f.argtypes = C.c_int64, [C.c_void_p]
+        return int(f(self.ptr))
+
     def counters(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         lib().ob_tree_counters(self.ptr, C.byref(a), C.byref(b), C.byref(c))

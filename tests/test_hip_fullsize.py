@@ -35,6 +35,7 @@ def test_config1_3x3_4096_games_100_sims():
     e.run()
     c = e.counters()
     assert c["games_finished"] == 4096 and c["error_slots"] == 0 and c["active_slots"] == 0
+    assert c["pool_resets"] == 0                      # the default pool never has to give a reused subtree up here
     got = e.fetch_samples()
     check_rows(got, 3, 3, 4096)
     # every move consumed min(4*n_valid!, 100) reads (+1 root expansion on the first move of a game)
@@ -131,7 +132,7 @@ def test_config4_9x9_complete_games_vs_oracle_rules():
     e.selfplay_start(n_games, 0)
     e.run()
     c = e.counters()
-    assert c["games_finished"] == n_games and c["error_slots"] == 0 and c["active_slots"] == 0
+    assert c["games_finished"] == n_games and c["error_slots"] == 0 and c["active_slots"] == 0 and c["pool_resets"] == 0
     got = e.fetch_samples()
     check_rows(got, 9, 9, n_games)
     cap = 10 * (1600 + 2)

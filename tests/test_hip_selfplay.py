@@ -367,7 +367,7 @@ def test_rows_do_not_depend_on_slot_scheduling():
 
 def test_tight_node_pool_falls_back_to_a_fresh_root_bit_exactly():
     """The reference's trees are unbounded Python objects; a slot's node pool is not.  When the subtree kept by tree reuse
-    (<= the chosen child's visit count nodes) plus the next search (mcts_num_read + 2) would not fit nodes_per_slot, the
+    (at most min(the chosen child's visits, the tree's nodes - 1) nodes) plus the next search (mcts_num_read + 2) would not fit nodes_per_slot, the
     driver starts that move from a fresh root -- exactly init_mcts_tree(..., reuse_tree=False) (mcts.py:176-179) -- and counts
     it.  The oracle replays every game move by move with that rule restated here: visit vectors, tree_size and the
     expansion count are bit-identical; with the default pool size the same games never need it."""
@@ -397,7 +397,8 @@ def test_tight_node_pool_falls_back_to_a_fresh_root_bit_exactly():
             assert np.array_equal(nv, got["visits"][i]), (gi, i)
             assert t.stats()[1] == got["tree_size"][i]
             mv = int(got["played"][i])
-            keep = int(nv[mv]) + sims + 2 <= cap        # the rule of csrc/tree.hip reroot(): kept nodes <= visits of the child
+            # the rule of csrc/tree.hip reroot(): kept nodes <= min(visits of the child, nodes of the whole tree - 1)
+            keep = min(int(nv[mv]), t.live_nodes() - 1) + sims + 2 <= cap
             resets += 0 if keep else 1
             t.advance(mv, reuse_tree=keep)
     assert resets == cnt["pool_resets"] and searches == cnt["expansions"]
