@@ -49,4 +49,4 @@ for g in range(last + 1):
                                "train_s": t2 - t1, "train_steps": steps, "ms_per_train_step_incl_data_and_validation": 1e3 * (t2 - t1) / max(1, steps),
                                "last_batch_idx": last_idx})
 coach.close()
-print(json.dumps(out))
+print(json.dumps(out))  # (train() prints its epoch lines before this one: take the last line)
