@@ -184,7 +184,7 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
         raise SystemExit("engine reported %d slots in error (node pool exhausted?)" % c1["error_slots"])
     m = {k: c1[k] - c0[k] for k in ("expansions", "nn_evals", "sum_path", "terminal_leaves", "moves_played", "cache_hits")}
     m.update(dt=dt, ms_total=c1["ms_total"], ms_nn_tower=c1["ms_nn_tower"], pool_high_water=c1["pool_high_water"],
-             nodes_per_slot=eng.cfg.nodes_per_slot or 10 * (args.sims + 2), E=eng.E, prep_steps=prep)
+             nodes_per_slot=eng.nodes_per_slot, E=eng.E, prep_steps=prep)
     if dist is not None:
         tdev = torch.tensor([float(m["expansions"]), float(m["nn_evals"]), dt], dtype=torch.float64).cuda()
         mx = tdev.clone()

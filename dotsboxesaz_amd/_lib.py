@@ -16,7 +16,7 @@ EVAL_FORMULA_HASH, EVAL_FORMULA_UNIFORM, EVAL_RESNET, EVAL_SIMPLENN, EVAL_EXTERN
 
 # every symbol include/dbaz.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "dbaz_last_error", "dbaz_version", "dbaz_create", "dbaz_destroy", "dbaz_sync",
+    "dbaz_last_error", "dbaz_version", "dbaz_nodes_per_slot", "dbaz_create", "dbaz_destroy", "dbaz_sync",
     "dbaz_rules_init", "dbaz_rules_valid_moves", "dbaz_rules_play", "dbaz_rules_result", "dbaz_rules_features",
     "dbaz_nn_configure", "dbaz_nn_select_model", "dbaz_nn_set_tensor", "dbaz_nn_commit", "dbaz_nn_predict",
     "dbaz_set_search_params", "dbaz_set_positions", "dbaz_search", "dbaz_search_timed", "dbaz_set_pending", "dbaz_search_begin", "dbaz_select", "dbaz_expand_backup",
@@ -82,6 +82,7 @@ def load():
     L.dbaz_last_error.argtypes = [vp]
     L.dbaz_last_error.restype = C.c_char_p
     L.dbaz_version.restype = C.c_int
+    L.dbaz_nodes_per_slot.argtypes = [vp]
     L.dbaz_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.dbaz_destroy.argtypes = [vp]
     L.dbaz_destroy.restype = None

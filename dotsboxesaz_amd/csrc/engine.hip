@@ -86,6 +86,7 @@ static int set_error(dbaz_engine *e, int code, const char *fmt, ...)
 
 extern "C" const char *dbaz_last_error(const dbaz_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 extern "C" int dbaz_version(void) { return 1; }
+extern "C" int dbaz_nodes_per_slot(const dbaz_engine *e) { return e ? e->g.cap : 0; }
 #ifdef DBAZ_STAMP
 // diagnostic builds (tools/stamp_build_run.sh) only: the shipped library does not export it, include/dbaz.h does not declare it
 int nn_read_stamps(NNState *nn, unsigned long long *out, int n_wg);
@@ -211,7 +212,15 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     g.rows = cfg->rows; g.cols = cfg->cols; g.H = g.rows + 1; g.W = g.cols + 1; g.HW = g.H * g.W;
     g.A = 2 * g.HW; g.AS = (g.A + 3) & ~3; g.B = g.rows * g.cols; g.E = 2 * g.rows * g.cols + g.rows + g.cols;
     g.node_dw = META_DW + 4 * g.AS;
-    g.cap = cfg->nodes_per_slot > 0 ? cfg->nodes_per_slot : 10 * (cfg->mcts_num_read + 2);
+    if (cfg->nodes_per_slot > 0) {
+        g.cap = cfg->nodes_per_slot;
+    } else {
+        // default: 10 searches' worth of nodes; up to 40 where all pools together stay within a third of the HBM (a trained
+        // network keeps most of its tree from move to move: dbaz_counters.pool_resets)
+        const long long base = 10LL * (cfg->mcts_num_read + 2), wide = 4 * base;
+        const long long fit = (96LL << 30) / ((long long)cfg->n_slots * g.node_dw * 4);
+        g.cap = (int)std::min(wide, std::max(base, fit));
+    }
     if (g.cap < 8) g.cap = 8;
     g.dmax = g.E + 4;
     for (int c = 0; c < g.W; c++) { int i = (1 * g.H + g.rows) * g.W + c; g.sentinel[i >> 6] |= 1ull << (i & 63); }

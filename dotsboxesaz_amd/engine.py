@@ -63,6 +63,7 @@ class Engine:
         rc = self._L.dbaz_create(C.byref(cfg), C.byref(self.h))
         if rc != _lib.OK:
             _lib.check(None, rc)
+        self.nodes_per_slot = int(self._L.dbaz_nodes_per_slot(self.h))  # the pool size in effect (0 asked for the default rule)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

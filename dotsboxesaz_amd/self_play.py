@@ -197,7 +197,7 @@ def _warn_pool_resets(engine, counters):
         import warnings
         warnings.warn("%d moves (of %d) were searched from a fresh root because the reused subtree did not leave mcts_num_read + 2 nodes "
                       "of the slot's pool free: raise nodes_per_slot (now %d) to keep the reference's tree reuse on every move"
-                      % (n, int(counters.get("moves_played", 0)), int(engine.cfg.nodes_per_slot) or 10 * (int(engine.cfg.mcts_num_read) + 2)))
+                      % (n, int(counters.get("moves_played", 0)), int(getattr(engine, "nodes_per_slot", 0) or engine.cfg.nodes_per_slot)))
 
 
 def collect_rows_device(engine, count, first):

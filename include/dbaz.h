@@ -54,7 +54,7 @@ typedef struct dbaz_engine dbaz_engine;
 typedef struct {
     int32_t rows, cols;
     int32_t n_slots;        /* concurrent games resident on the GPU */
-    int32_t nodes_per_slot; /* node pool per game; 0 = 10*(mcts_num_read+2) */
+    int32_t nodes_per_slot; /* node pool per game; 0 = 10*(mcts_num_read+2), up to 4x that while all pools fit 96 GiB */
     int32_t mcts_num_read;  /* self_play.mcts.mcts_num_read */
     double cpuct, cpuct_base; /* self_play.mcts.mcts_cpuct */
     double noise_alpha, noise_coeff; /* self_play.noise */
@@ -109,6 +109,7 @@ typedef struct {
 
 const char *dbaz_last_error(const dbaz_engine *e); /* e may be NULL: error of the last dbaz_create */
 int dbaz_version(void);
+int dbaz_nodes_per_slot(const dbaz_engine *e); /* the node pool size in effect (dbaz_config.nodes_per_slot = 0: the default rule) */
 
 int dbaz_create(const dbaz_config *cfg, dbaz_engine **out);
 void dbaz_destroy(dbaz_engine *e);
