@@ -78,6 +78,8 @@ struct Slot {
     int32_t wave_sims;       // K > 1 search: simulations selected in the current wave, waiting for expand/backup
     int32_t first_wave;      // K > 1 search: the first wave of a UCT_search call is min(K, A) wide (mcts.py:228-229)
     int32_t pool_resets;     // self-play driver: moves whose kept subtree would not have left room for the next search (fresh root instead)
+    int32_t eval_pos;        // position of this step's leaf in the evaluation list (k_select)
+    int32_t pending;         // 1 = the leaf was selected in an earlier step and its evaluation deferred (SearchCfg.eval_round)
 };
 
 // device-side reduction of the Slot array (dbaz_get_counters / dbaz_run poll this instead of copying every Slot)
@@ -125,6 +127,9 @@ struct SearchCfg {
     int quick_reads;         // read budget of the quick plies (dbaz_selfplay_quickplay)
     int pending;             // K > 1 search: width of a wave (<= TreeBufs.kmax), dbaz_set_pending
     int virtual_visits;      // K > 1 search: 1 = a simulation's visit is counted on its path at selection, 0 = at backup (the reference)
+    // full rounds only (self-play stepping with a network evaluator): the evaluation list is cut back to a multiple of eval_round
+    // leaves whenever at most eval_defer_max would be left over; the slots behind the cut keep their leaf and ask again next step
+    int eval_round, eval_defer_max; // 0: every leaf is evaluated in the step that selected it
 };
 
 // device buffer bundle handed to the tree kernels
@@ -140,7 +145,7 @@ struct TreeBufs {
     float *evalV;      // [n_slots]
     int32_t *eval_list;// [n_slots] compacted slots needing an NN evaluation (model 0)
     int32_t *eval_list2;// [n_slots] same for model 1 (match play)
-    int32_t *n_eval;   // [2] list lengths
+    int32_t *n_eval;   // [4] list lengths of the two models; [2] leaves model 0's network evaluates this step (after k_eval_cut), [3] leaves asked for
     int32_t *pend;     // [n_slots][cap] ring: dropped nodes waiting for the collector (their child rows are still needed)
     int32_t *freel;    // [n_slots][cap] stack: node indices ready for reuse
     // search with K > 1 pending evaluations per tree (buffers exist when dbaz_config.max_pending_evals > 1)

@@ -57,6 +57,7 @@ struct dbaz_engine {
     SlotSummary *d_sum = nullptr;
     bool selfplay = false;
     bool late_join = false; // the driver pass is joined behind the network launch instead of in front of it (sim_step)
+    int eval_round = 0, eval_defer_max = 0; // full rounds only (k_eval_cut): set when the network is committed
     bool search_open = false;
     int search_iters_left = 0;
     // packed replay rows
@@ -478,6 +479,16 @@ extern "C" int dbaz_nn_commit(dbaz_engine *e)
     int r = nn_commit(e->nn, e->stream, err);
     if (r) return set_error(e, r, "%s", err.c_str());
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
+    if (e->nn == e->nns[0]) {
+        nn_round_info(e->nn, &e->eval_round, &e->eval_defer_max);
+        // measurement / test aids: DBAZ_EVAL_ROUND=0 switches the cut off, =r[,d] forces a round size (and the largest left-over
+        // that is put off) so that small test runs go through the same path
+        if (const char *v = getenv("DBAZ_EVAL_ROUND")) {
+            int rr = 0, dd = -1;
+            if (sscanf(v, "%d,%d", &rr, &dd) >= 1) { e->eval_round = rr; e->eval_defer_max = dd >= 0 ? dd : rr - 1; }
+        }
+        if (e->eval_defer_max <= 0) e->eval_round = 0;
+    }
     return DBAZ_OK;
 }
 extern "C" int dbaz_nn_predict(dbaz_engine *e, int32_t n, const float *X, float *p, float *v)
@@ -624,7 +635,14 @@ static int sim_step(dbaz_engine *e, bool with_driver)
         tree_launch_advance_auto(e->stream2, e->g, e->sc, e->B, e->n_slots);
         HIP_CHECK_RET(e, hipEventRecord(e->ev_join, e->stream2));
     }
+    // full rounds only (see k_eval_cut): self-play stepping, one network, one leaf per slot
+    e->sc.eval_round = 0;
+    if (with_driver && use_nn && !use_nn2 && !e->sc.match_play && e->B.kmax <= 1 && e->eval_round > 0 && e->n_slots > e->eval_round) {
+        e->sc.eval_round = e->eval_round;
+        e->sc.eval_defer_max = e->eval_defer_max;
+    }
     tree_launch_select(s, e->g, e->sc, e->B, e->n_slots); // (the lists' counters were zeroed by the previous k_expand_backup)
+    if (e->sc.eval_round > 0) tree_launch_eval_cut(s, e->sc, e->B);
     const bool late_join = with_driver && e->late_join;
     if (with_driver && !late_join) HIP_CHECK_RET(e, hipStreamWaitEvent(s, e->ev_join, 0));
     if (use_nn) {

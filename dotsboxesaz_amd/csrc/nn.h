@@ -19,6 +19,9 @@ bool nn_ready(const NNState *nn);
 void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *list_dev, const int32_t *n_dev,
                 int max_n, float *P, float *V, int AS, hipEvent_t ev_begin, hipEvent_t ev_end);
 double nn_flops_per_sample(const NNState *nn);
+// samples of one full round of the main tower launch (CUs x samples per workgroup), and the largest left-over that nn_forward
+// would hand to a remainder launch (0: no remainder launches for this geometry)
+void nn_round_info(const NNState *nn, int *round, int *rem_max);
 const char *nn_tower_kernel_name(const NNState *nn);
 // f16x3 mode: non-zero once an activation exceeded f16's range (results invalid: use precision 0)
 int nn_overflowed(NNState *nn);

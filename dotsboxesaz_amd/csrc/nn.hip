@@ -2302,6 +2302,15 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     hipLaunchKernelGGL(k_head_fc, dim3((max_n + 16 * HEAD_MT - 1) / (16 * HEAD_MT)), dim3(256), nn->fc_lds, s, g, ha);
 }
 
+void nn_round_info(const NNState *nn, int *round, int *rem_max)
+{
+    *round = 0; *rem_max = 0;
+    if (!nn || nn->kind != DBAZ_EVAL_RESNET || nn->mf32) return;
+    *round = nn->cus * (nn->c2 ? nn->S_c2 : nn->S);
+    const int s_rem = nn->c2 ? nn->S : std::max(nn->S_big, std::max(nn->S_mid, nn->S_small));
+    *rem_max = nn->cus * s_rem;
+}
+
 double nn_flops_per_sample(const NNState *nn)
 {
     // 2*MAC of conv + FC layers: conv0, 2*blocks tower convs, head convs, FCs

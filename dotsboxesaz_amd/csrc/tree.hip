@@ -576,6 +576,11 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
         return -1;
     if ((int)(unsigned)(pw >> 32) == cfg.step && cfg.driver_concurrent) // search started by this step's driver pass (see set_phase_stamped)
         return -1;
+    if (cfg.eval_round > 0 && S->pending) {
+        // the leaf of an earlier step whose evaluation was put off (k_eval_cut): path, leaf and features are still in place
+        if (lane == 0) S->sel_step = cfg.step;
+        return S->model;
+    }
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
     PathEnt *path = B.path + (size_t)slot * g.dmax;
     const double *rprior = B.root_prior + (size_t)slot * g.AS;
@@ -833,7 +838,24 @@ __global__ void __launch_bounds__(WAVE * SELECT_WAVES) k_select(Geo g, SearchCfg
     __syncthreads();
     if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(B.n_eval + threadIdx.x, s_cnt[threadIdx.x]);
     __syncthreads();
-    if (my >= 0) (model ? B.eval_list2 : B.eval_list)[s_base[model] + my] = slot;
+    if (my >= 0) {
+        (model ? B.eval_list2 : B.eval_list)[s_base[model] + my] = slot;
+        B.slots[slot].eval_pos = s_base[model] + my;
+    }
+}
+
+// Full rounds only.  A network launch costs whole rounds of workgroups (nn.hip): 5 306 leaves are four rounds of 1 280 and a
+// remainder round that costs 40 % of a round for 3.5 % of the leaves.  When at most eval_defer_max leaves would be left behind the
+// last full round, the list is cut there; the slots behind the cut keep their selected leaf and ask again in the next step, where
+// they are among the first in the list.  Every game plays the same moves -- only WHEN a slot's simulation completes changes.
+__global__ void k_eval_cut(SearchCfg cfg, TreeBufs B)
+{
+    const int n = B.n_eval[0];
+    const int n_full = (n / cfg.eval_round) * cfg.eval_round;
+    const int use = (n_full > 0 && n - n_full <= cfg.eval_defer_max) ? n_full : n;
+    B.n_eval[0] = use;
+    B.n_eval[2] = use;
+    B.n_eval[3] = n;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1160,6 +1182,12 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
         const int ev = (cfg.match_play && S->model) ? cfg.evaluator2 : cfg.evaluator;
         const bool formula = ev == DBAZ_EVAL_FORMULA_HASH || ev == DBAZ_EVAL_FORMULA_UNIFORM;
         if (B.tt) hit = S->leaf_hit;
+        if (cfg.eval_round > 0 && hit < 0 && !formula) {
+            // behind this step's cut (k_eval_cut): the network has not seen the leaf; keep it and ask again next step
+            const bool late = S->eval_pos >= B.n_eval[2];
+            if (lane == 0) S->pending = late ? 1 : 0;
+            if (late) return;
+        }
         if (hit >= 0) {
             // transposition: the twin's row is masked(p) / sum for the same valid moves, its v the same network output
             const uint32_t *tw = node_ptr(pool, g, hit);
@@ -1413,6 +1441,7 @@ __global__ void __launch_bounds__(WAVE) k_set_positions(Geo g, SearchCfg cfg, Tr
         S->n_search = S->sum_path = S->n_eval = S->n_term = S->n_hit = 0;
         S->pool_high = 1;
         S->pool_resets = 0;
+        S->pending = 0;
     }
 }
 
@@ -1528,6 +1557,7 @@ __global__ void __launch_bounds__(WAVE) k_selfplay_start(Geo g, SearchCfg cfg, T
         S->n_search = S->sum_path = S->n_eval = S->n_term = S->n_hit = 0;
         S->pool_high = 1;
         S->pool_resets = 0;
+        S->pending = 0;
     }
     // deterministic initial assignment: slot i takes game first+i (the dispenser starts behind them)
     long long gidx = B.first_game + slot;
@@ -1909,6 +1939,7 @@ void tree_launch_advance_auto(hipStream_t s, const Geo &g, const SearchCfg &c, c
     hipLaunchKernelGGL(k_driver_scan, dim3((n_slots + 255) / 256), dim3(256), 0, s, c, B, n_slots);
     hipLaunchKernelGGL(k_advance_auto, dim3(n_slots < 1024 ? n_slots : 1024), dim3(WAVE), 0, s, g, c, B);
 }
+void tree_launch_eval_cut(hipStream_t s, const SearchCfg &c, const TreeBufs &B) { hipLaunchKernelGGL(k_eval_cut, dim3(1), dim3(1), 0, s, c, B); }
 void tree_launch_get_roots(hipStream_t s, const Geo &g, const TreeBufs &B, int n_slots, double *priors, float *tv,
                            int32_t *nv, int32_t *changed, int32_t *stats, float *q, float *root_tv, int32_t *root_nv,
                            uint64_t *edges, int16_t *b2c2, int8_t *to_play, int8_t *just_played, int8_t *result,

@@ -146,7 +146,8 @@ def test_config4_9x9_complete_games_vs_oracle_rules():
     e.close()
 
 
-def test_config4_9x9_network_steps():
+@pytest.mark.parametrize("cut", [False, True])
+def test_config4_9x9_network_steps(monkeypatch, cut):
     """The fused trunk on 10x10 images (2 samples per workgroup, 13 position tiles) inside the self-play step at 2048
     slots: every expansion is a network evaluation, a cache hit or a terminal leaf."""
     import torch
@@ -156,15 +157,24 @@ def test_config4_9x9_network_steps():
     m = nn_ref.ResNetZeroRef(9, 9, 64, 4)
     nn_ref.randomize_bn(m, 2)
     K, n = 12, 2048
+    if not cut:
+        monkeypatch.setenv("DBAZ_EVAL_ROUND", "0")   # every leaf is evaluated in the step that selected it
     e = Engine(9, 9, n, mcts_num_read=1600, noise=(0.8, 0.25), evaluator="resnet", nn_precision=1, seed=3)
     e.load_state_dict(m.state_dict(), "resnet", 64, 4, 16, 8)
     e.selfplay_fastforward((np.arange(n) * 37) % 120)
     e.selfplay_start(1 << 30, 0)
     e.step(K)
     c = e.counters()
-    assert c["error_slots"] == 0 and c["expansions"] == n * K
+    assert c["error_slots"] == 0
     assert c["nn_evals"] + c["cache_hits"] + c["terminal_leaves"] == c["expansions"] and c["nn_evals"] > n * K // 2
     r = e.roots()
-    assert (r["root_nv"] == K).all() and (r["visits"].sum(1) == K - 1).all()
+    if cut:
+        # full rounds only (k_eval_cut): a slot whose leaf falls behind the step's last full round of 512 (when at most 256
+        # would be left over) completes that search a step later -- never more than one search per step, none lost
+        assert n * K * 3 // 4 < c["expansions"] < n * K
+        assert (r["root_nv"] <= K).all() and (r["root_nv"] >= K // 2).all() and (r["visits"].sum(1) == r["root_nv"] - 1).all()
+    else:
+        assert c["expansions"] == n * K
+        assert (r["root_nv"] == K).all() and (r["visits"].sum(1) == K - 1).all()
     assert np.isfinite(r["total_value"]).all() and np.allclose(r["priors"].sum(1), 1.0, atol=0.26)
     e.close()

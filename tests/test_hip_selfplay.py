@@ -365,6 +365,37 @@ def test_rows_do_not_depend_on_slot_scheduling():
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("rnd", ["16,15", "16,6", "7,6"])
+def test_full_rounds_only_changes_nothing_but_the_schedule(monkeypatch, rnd):
+    """k_eval_cut: when a step's evaluation list would leave a few leaves behind the last full round of network workgroups,
+    those leaves are put off to the next step (their slots keep the selected leaf).  Forced here with tiny rounds
+    (DBAZ_EVAL_ROUND=round,largest left-over that is put off): the 96 games' rows, visit counts and statistics are
+    bit-identical to the run without the cut; only the number of steps differs."""
+    import torch
+    from dotsboxesaz_amd.engine import Engine
+    from dotsboxesaz_amd import nn as dnn
+    torch.manual_seed(4)
+    model = dnn.ResNetZero(dnn.resnet_params(3, 3, 32, 2, 4, 8))
+    out, steps, exps = [], [], []
+    for env in ("0", rnd):
+        monkeypatch.setenv("DBAZ_EVAL_ROUND", env)
+        e = Engine(3, 3, 40, mcts_num_read=48, noise=(0.8, 0.25), reuse_tree=True, evaluator="resnet", seed=11)
+        e.load_state_dict(model.state_dict(), "resnet", **model.shape)
+        e.selfplay_start(96, 0)
+        e.run()
+        c = e.counters()
+        assert c["games_finished"] == 96 and c["error_slots"] == 0 and c["active_slots"] == 0
+        out.append(e.fetch_samples())
+        steps.append(c["steps"])
+        exps.append((c["expansions"], c["nn_evals"], c["cache_hits"], c["terminal_leaves"]))
+        e.close()
+    a, b = out
+    assert len(a["z"]) == len(b["z"]) and exps[0] == exps[1]
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert steps[1] > steps[0]        # leaves were put off (and the games still came out the same)
+
+
 def test_tight_node_pool_falls_back_to_a_fresh_root_bit_exactly():
     """The reference's trees are unbounded Python objects; a slot's node pool is not.  When the subtree kept by tree reuse
     (at most min(the chosen child's visits, the tree's nodes - 1) nodes) plus the next search (mcts_num_read + 2) would not fit nodes_per_slot, the
