@@ -577,9 +577,16 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
     if ((int)(unsigned)(pw >> 32) == cfg.step && cfg.driver_concurrent) // search started by this step's driver pass (see set_phase_stamped)
         return -1;
     if (cfg.eval_round > 0 && S->pending) {
-        // the leaf of an earlier step whose evaluation was put off (k_eval_cut): path, leaf and features are still in place
-        if (lane == 0) S->sel_step = cfg.step;
-        return S->model;
+        // the leaf of an earlier step whose evaluation was put off (k_eval_cut): path, leaf and features are still in place.
+        // It takes its place in the list at once -- ahead of every leaf that is still being selected, so it cannot be put off
+        // again (the workgroup's batched append below happens after the slowest of its 16 descents)
+        if (lane == 0) {
+            S->sel_step = cfg.step;
+            const int pos = atomicAdd(B.n_eval, 1);
+            B.eval_list[pos] = slot;
+            S->eval_pos = pos;
+        }
+        return -1;
     }
     uint32_t *pool = B.nodes + (size_t)slot * g.cap * g.node_dw;
     PathEnt *path = B.path + (size_t)slot * g.dmax;
