@@ -514,7 +514,7 @@ def main():
             "per_gpu": m["exp_all"] / m["dt_max"] / world,
             "expansions_per_step": m["exp_all"] / max(1, args.steps) / world,
             "step_note": "a step = one simulation for every game whose leaf is evaluated (or needs no network) in it; with the "
-                         "network's evaluation list cut back to full rounds of workgroups (k_eval_cut, DESIGN 4) the slots behind "
+                         "network's evaluation list cut back to full rounds of workgroups (DESIGN 4) the slots behind "
                          "the cut complete theirs one step later: expansions_per_step < slots, value counts completed searches only",
             "nn_evals_per_sec": m["evals_all"] / m["dt_max"],
             "mean_path_len": spath / max(1, exp), "terminal_leaf_fraction": term / max(1, exp),

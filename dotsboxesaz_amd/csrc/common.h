@@ -79,7 +79,7 @@ struct Slot {
     int32_t first_wave;      // K > 1 search: the first wave of a UCT_search call is min(K, A) wide (mcts.py:228-229)
     int32_t pool_resets;     // self-play driver: moves whose kept subtree would not have left room for the next search (fresh root instead)
     int32_t eval_pos;        // position of this step's leaf in the evaluation list (k_select)
-    int32_t pending;         // 1 = the leaf was selected in an earlier step and its evaluation deferred (SearchCfg.eval_round)
+    int32_t pending;         // 1 = the leaf was selected in an earlier step and its evaluation put off (SearchCfg.eval_round)
 };
 
 // device-side reduction of the Slot array (dbaz_get_counters / dbaz_run poll this instead of copying every Slot)
@@ -145,7 +145,7 @@ struct TreeBufs {
     float *evalV;      // [n_slots]
     int32_t *eval_list;// [n_slots] compacted slots needing an NN evaluation (model 0)
     int32_t *eval_list2;// [n_slots] same for model 1 (match play)
-    int32_t *n_eval;   // [4] list lengths of the two models; [2] leaves model 0's network evaluates this step (after k_eval_cut), [3] leaves asked for
+    int32_t *n_eval;   // [4] list lengths of the two models; [2] leaves model 0's network took this step (k_head_fc, full rounds only)
     int32_t *pend;     // [n_slots][cap] ring: dropped nodes waiting for the collector (their child rows are still needed)
     int32_t *freel;    // [n_slots][cap] stack: node indices ready for reuse
     // search with K > 1 pending evaluations per tree (buffers exist when dbaz_config.max_pending_evals > 1)

@@ -57,7 +57,7 @@ struct dbaz_engine {
     SlotSummary *d_sum = nullptr;
     bool selfplay = false;
     bool late_join = false; // the driver pass is joined behind the network launch instead of in front of it (sim_step)
-    int eval_round = 0, eval_defer_max = 0; // full rounds only (k_eval_cut): set when the network is committed
+    int eval_round = 0, eval_defer_max = 0; // full rounds only (tree.hip, above k_select): set when the network is committed
     bool search_open = false;
     int search_iters_left = 0;
     // packed replay rows
@@ -635,20 +635,20 @@ static int sim_step(dbaz_engine *e, bool with_driver)
         tree_launch_advance_auto(e->stream2, e->g, e->sc, e->B, e->n_slots);
         HIP_CHECK_RET(e, hipEventRecord(e->ev_join, e->stream2));
     }
-    // full rounds only (see k_eval_cut): self-play stepping, one network, one leaf per slot
+    // full rounds only (tree.hip, above k_select): self-play stepping, one network, one leaf per slot
     e->sc.eval_round = 0;
     if (with_driver && use_nn && !use_nn2 && !e->sc.match_play && e->B.kmax <= 1 && e->eval_round > 0 && e->n_slots > e->eval_round) {
         e->sc.eval_round = e->eval_round;
         e->sc.eval_defer_max = e->eval_defer_max;
     }
     tree_launch_select(s, e->g, e->sc, e->B, e->n_slots); // (the lists' counters were zeroed by the previous k_expand_backup)
-    if (e->sc.eval_round > 0) tree_launch_eval_cut(s, e->sc, e->B);
     const bool late_join = with_driver && e->late_join;
     if (with_driver && !late_join) HIP_CHECK_RET(e, hipStreamWaitEvent(s, e->ev_join, 0));
     if (use_nn) {
         hipEvent_t a = nullptr, b = nullptr;
         if (e->timing) { a = next_event(e); b = next_event(e); }
-        nn_forward(e->nns[0], s, e->B.feat, e->B.eval_list, e->B.n_eval, e->n_slots, e->B.evalP, e->B.evalV, e->g.AS, a, b);
+        nn_forward(e->nns[0], s, e->B.feat, e->B.eval_list, e->B.n_eval, e->n_slots, e->B.evalP, e->B.evalV, e->g.AS, a, b,
+                   e->sc.eval_round, e->sc.eval_defer_max, e->B.n_eval + 2);
         e->nn_launches++;
     }
     if (use_nn2) {

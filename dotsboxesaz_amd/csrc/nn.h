@@ -16,8 +16,11 @@ bool nn_ready(const NNState *nn);
 // Evaluate samples feat[list[j]] (float32 planes [3][H][W], j < *n_dev <= max_n) and scatter
 // softmax policy to P[list[j]*AS + a] and tanh value to V[list[j]].  list == nullptr: identity.
 // ev_begin/ev_end (optional) are recorded around the conv tower on `s`.
+// cut_round / cut_defer (self-play stepping; 0 = off): only cut_n(*n_dev) leaves of the list are evaluated -- full rounds of
+// workgroups -- and that count is left in *n_used for k_expand_backup ("full rounds only")
 void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *list_dev, const int32_t *n_dev,
-                int max_n, float *P, float *V, int AS, hipEvent_t ev_begin, hipEvent_t ev_end);
+                int max_n, float *P, float *V, int AS, hipEvent_t ev_begin, hipEvent_t ev_end, int cut_round = 0, int cut_defer = 0,
+                int32_t *n_used = nullptr);
 double nn_flops_per_sample(const NNState *nn);
 // samples of one full round of the main tower launch (CUs x samples per workgroup), and the largest left-over that nn_forward
 // would hand to a remainder launch (0: no remainder launches for this geometry)

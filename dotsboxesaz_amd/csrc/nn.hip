@@ -745,6 +745,15 @@ __device__ __forceinline__ float act_load(const float *lds, int row, int c)
     }
 }
 
+// Full rounds only (engine: self-play stepping): the leaves the network takes from a list of n -- every kernel of a step applies
+// the same rule to the same count, so no launch of its own is needed for it (see "Full rounds only" in tree.hip)
+__device__ __forceinline__ int cut_n(int n, int round, int defer_max)
+{
+    if (round <= 0) return n;
+    const int n_full = (n / round) * round;
+    return (n_full > 0 && n - n_full <= defer_max) ? n_full : n;
+}
+
 struct TowerArgs {
     const float *feat;       // [slot][3][HW] leaf feature planes
     const int32_t *list;     // compacted slot list (nullptr: identity)
@@ -766,6 +775,7 @@ struct TowerArgs {
     int S, nblocks, hc;
     // tail handling (see nn_forward): role 0 = main launch, 1 / 2 = tail launches with fewer samples per workgroup
     int role, S_main, S_small, S_mid, S_big, S_huge, cus;
+    int cut_round, cut_defer; // cut_n's rule for this step's list (0: every leaf)
     unsigned long long *stamp_out; // diagnostic build only
 };
 
@@ -1132,7 +1142,7 @@ template <int C, int NTA, int NTB, int PREC, int MF = 0>
 __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int n = *a.n_dev;
+    const int n = cut_n(*a.n_dev, a.cut_round, a.cut_defer);
     const int S = a.S;
     // Every workgroup of a launch takes the same time, so the launch costs ceil(workgroups / CUs) rounds and a
     // nearly empty last round costs a full one.  The samples beyond the last FULL round of the main launch are
@@ -1195,7 +1205,7 @@ template <int C>
 __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_rem(Geo g, TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int n = *a.n_dev;
+    const int n = cut_n(*a.n_dev, a.cut_round, a.cut_defer);
     int n_full;
     const int mode = tower_split(a, n, n_full);
     if (mode == 0) return;
@@ -1414,6 +1424,8 @@ struct HeadArgs {
     float *P, *V;
     int K, KP /*K padded to 16*/, RS4 /*LDS row stride, float4 units*/, ntp, ntv, vf, AS;
     int value_direct; // SimpleNN: value = tanh(value_fc(x)), no hidden layer
+    int cut_round, cut_defer; // cut_n's rule (0: every leaf); n_used (optional) receives the count the step's network took
+    int32_t *n_used;
 };
 
 // K is split over the 4 waves (wave w owns the 16-wide k chunks kc = w, w+4, ...).  Nothing is staged:
@@ -1461,7 +1473,8 @@ __global__ void __launch_bounds__(256) k_head_fc(Geo g, HeadArgs h)
 {
     extern __shared__ __attribute__((aligned(16))) float ldsf[];
     constexpr int SPW = 16 * HEAD_MT; // samples per workgroup
-    const int n = *h.n_dev;
+    const int n = cut_n(*h.n_dev, h.cut_round, h.cut_defer);
+    if (h.n_used && blockIdx.x == 0 && threadIdx.x == 0) *h.n_used = n; // k_expand_backup: list positions >= n ask again next step
     const int j0 = blockIdx.x * SPW;
     if (j0 >= n) return;
     const int ns = min(SPW, n - j0);
@@ -2209,7 +2222,7 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
 }
 
 void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *list_dev, const int32_t *n_dev, int max_n,
-                float *P, float *V, int AS, hipEvent_t ev_begin, hipEvent_t ev_end)
+                float *P, float *V, int AS, hipEvent_t ev_begin, hipEvent_t ev_end, int cut_round, int cut_defer, int32_t *n_used)
 {
     const Geo &g = nn->g;
     const int hc = nn->hc, HW = g.HW;
@@ -2235,7 +2248,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
         HeadArgs ha;
         ha.list = list_dev; ha.n_dev = n_dev; ha.hact = nn->hact; ha.wfc = nn->wfc; ha.bfc = nn->bfc; ha.wv1 = nn->wv1; ha.bv1 = nn->bv1;
         ha.P = P; ha.V = V; ha.K = 256; ha.KP = 256; ha.RS4 = nn->RS4; ha.ntp = nn->ntp; ha.ntv = nn->ntv; ha.vf = 0; ha.AS = AS;
-        ha.value_direct = 1;
+        ha.value_direct = 1; ha.cut_round = 0; ha.cut_defer = 0; ha.n_used = nullptr;
         hipLaunchKernelGGL(k_head_fc, dim3((max_n + 16 * HEAD_MT - 1) / (16 * HEAD_MT)), dim3(256), nn->fc_lds, s, g, ha);
         return;
     }
@@ -2246,6 +2259,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     ta.stamp_out = nn->stamp_out;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.S_big = nn->S_big; ta.S_huge = 0; ta.cus = nn->cus;
+    ta.cut_round = cut_round; ta.cut_defer = cut_defer;
     ta.role = 0; ta.S = nn->S;
     if (nn->c2) {
         // two cout tiles per wave (default for 64 channels) for the FULL rounds; what is left behind the last full round goes
@@ -2298,7 +2312,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     HeadArgs ha;
     ha.list = list_dev; ha.n_dev = n_dev; ha.hact = nn->hact; ha.wfc = nn->wfc; ha.bfc = nn->bfc; ha.wv1 = nn->wv1; ha.bv1 = nn->bv1;
     ha.P = P; ha.V = V; ha.K = hc * HW; ha.KP = nn->KP; ha.RS4 = nn->RS4; ha.ntp = nn->ntp; ha.ntv = nn->ntv; ha.vf = nn->vf; ha.AS = AS;
-    ha.value_direct = 0;
+    ha.value_direct = 0; ha.cut_round = cut_round; ha.cut_defer = cut_defer; ha.n_used = n_used;
     hipLaunchKernelGGL(k_head_fc, dim3((max_n + 16 * HEAD_MT - 1) / (16 * HEAD_MT)), dim3(256), nn->fc_lds, s, g, ha);
 }
 

@@ -14,7 +14,6 @@ void tree_launch_advance_manual(hipStream_t s, const Geo &g, const SearchCfg &c,
                                 const int32_t *moves_dev, int reuse);
 void tree_launch_selfplay_start(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots);
 void tree_launch_advance_auto(hipStream_t s, const Geo &g, const SearchCfg &c, const TreeBufs &B, int n_slots);
-void tree_launch_eval_cut(hipStream_t s, const SearchCfg &c, const TreeBufs &B);
 void tree_launch_get_roots(hipStream_t s, const Geo &g, const TreeBufs &B, int n_slots, double *priors, float *tv,
                            int32_t *nv, int32_t *changed, int32_t *stats, float *q, float *root_tv, int32_t *root_nv,
                            uint64_t *edges, int16_t *b2c2, int8_t *to_play, int8_t *just_played, int8_t *result,

@@ -577,7 +577,7 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
     if ((int)(unsigned)(pw >> 32) == cfg.step && cfg.driver_concurrent) // search started by this step's driver pass (see set_phase_stamped)
         return -1;
     if (cfg.eval_round > 0 && S->pending) {
-        // the leaf of an earlier step whose evaluation was put off (k_eval_cut): path, leaf and features are still in place.
+        // the leaf of an earlier step whose evaluation was put off (full rounds only): path, leaf and features are still in place.
         // It takes its place in the list at once -- ahead of every leaf that is still being selected, so it cannot be put off
         // again (the workgroup's batched append below happens after the slowest of its 16 descents)
         if (lane == 0) {
@@ -851,19 +851,12 @@ __global__ void __launch_bounds__(WAVE * SELECT_WAVES) k_select(Geo g, SearchCfg
     }
 }
 
-// Full rounds only.  A network launch costs whole rounds of workgroups (nn.hip): 5 306 leaves are four rounds of 1 280 and a
-// remainder round that costs 40 % of a round for 3.5 % of the leaves.  When at most eval_defer_max leaves would be left behind the
-// last full round, the list is cut there; the slots behind the cut keep their selected leaf and ask again in the next step, where
-// they are among the first in the list.  Every game plays the same moves -- only WHEN a slot's simulation completes changes.
-__global__ void k_eval_cut(SearchCfg cfg, TreeBufs B)
-{
-    const int n = B.n_eval[0];
-    const int n_full = (n / cfg.eval_round) * cfg.eval_round;
-    const int use = (n_full > 0 && n - n_full <= cfg.eval_defer_max) ? n_full : n;
-    B.n_eval[0] = use;
-    B.n_eval[2] = use;
-    B.n_eval[3] = n;
-}
+// Full rounds only (SearchCfg.eval_round > 0).  A network launch costs whole rounds of workgroups (nn.hip): 5 306 leaves are four
+// rounds of 1 280 and a remainder round that costs 40 % of a round for 3.5 % of the leaves.  When at most eval_defer_max leaves
+// would be left behind the last full round, the network kernels take only the full rounds (nn.hip cut_n: every kernel of the step
+// applies the same rule to the same count; k_head_fc leaves the count in n_eval[2]); the slots behind the cut keep their selected
+// leaf -- k_expand_backup sets Slot::pending -- and ask again in the next step, at the head of the list (select_one).  Every game
+// plays the same moves: only WHEN a slot's simulation completes changes.
 
 // ------------------------------------------------------------------------------------
 // UCT_search with K > 1 pending evaluations on ONE tree (mcts.py:228-239; players.AZPlayer).
@@ -1190,7 +1183,7 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup(Geo g, SearchCfg cfg, Tr
         const bool formula = ev == DBAZ_EVAL_FORMULA_HASH || ev == DBAZ_EVAL_FORMULA_UNIFORM;
         if (B.tt) hit = S->leaf_hit;
         if (cfg.eval_round > 0 && hit < 0 && !formula) {
-            // behind this step's cut (k_eval_cut): the network has not seen the leaf; keep it and ask again next step
+            // behind this step's cut: the network has not seen the leaf; keep it and ask again next step
             const bool late = S->eval_pos >= B.n_eval[2];
             if (lane == 0) S->pending = late ? 1 : 0;
             if (late) return;
@@ -1946,7 +1939,6 @@ void tree_launch_advance_auto(hipStream_t s, const Geo &g, const SearchCfg &c, c
     hipLaunchKernelGGL(k_driver_scan, dim3((n_slots + 255) / 256), dim3(256), 0, s, c, B, n_slots);
     hipLaunchKernelGGL(k_advance_auto, dim3(n_slots < 1024 ? n_slots : 1024), dim3(WAVE), 0, s, g, c, B);
 }
-void tree_launch_eval_cut(hipStream_t s, const SearchCfg &c, const TreeBufs &B) { hipLaunchKernelGGL(k_eval_cut, dim3(1), dim3(1), 0, s, c, B); }
 void tree_launch_get_roots(hipStream_t s, const Geo &g, const TreeBufs &B, int n_slots, double *priors, float *tv,
                            int32_t *nv, int32_t *changed, int32_t *stats, float *q, float *root_tv, int32_t *root_nv,
                            uint64_t *edges, int16_t *b2c2, int8_t *to_play, int8_t *just_played, int8_t *result,

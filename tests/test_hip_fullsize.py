@@ -169,7 +169,7 @@ def test_config4_9x9_network_steps(monkeypatch, cut):
     assert c["nn_evals"] + c["cache_hits"] + c["terminal_leaves"] == c["expansions"] and c["nn_evals"] > n * K // 2
     r = e.roots()
     if cut:
-        # full rounds only (k_eval_cut): a slot whose leaf falls behind the step's last full round of 512 (when at most 256
+        # full rounds only (nn.hip cut_n): a slot whose leaf falls behind the step's last full round of 512 (when at most 256
         # would be left over) completes that search a step later -- never more than one search per step, none lost
         assert n * K * 3 // 4 < c["expansions"] < n * K
         assert (r["root_nv"] <= K).all() and (r["root_nv"] >= K // 2).all() and (r["visits"].sum(1) == r["root_nv"] - 1).all()

@@ -367,7 +367,7 @@ def test_rows_do_not_depend_on_slot_scheduling():
 
 @pytest.mark.parametrize("rnd", ["16,15", "16,6", "7,6"])
 def test_full_rounds_only_changes_nothing_but_the_schedule(monkeypatch, rnd):
-    """k_eval_cut: when a step's evaluation list would leave a few leaves behind the last full round of network workgroups,
+    """Full rounds only (nn.hip cut_n): when a step's evaluation list would leave a few leaves behind the last full round of network workgroups,
     those leaves are put off to the next step (their slots keep the selected leaf).  Forced here with tiny rounds
     (DBAZ_EVAL_ROUND=round,largest left-over that is put off): the 96 games' rows, visit counts and statistics are
     bit-identical to the run without the cut; only the number of steps differs."""
