@@ -16,7 +16,7 @@ import sys
 def main(trace, bench_json, K, out):
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    main_k = max((r["Kernel_Name"] for r in rows if "k_tower<" in r["Kernel_Name"]),
+    main_k = max((r["Kernel_Name"] for r in rows if "k_tower" in r["Kernel_Name"]),
                  key=lambda k: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"] == k))
     idx = [i for i, r in enumerate(rows) if r["Kernel_Name"] == main_k]
     first = idx[-K]
