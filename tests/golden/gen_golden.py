@@ -20,6 +20,7 @@ Outputs are data only (inputs + the reference's outputs):
     train.npz      SymmetriesGenerator, dataset build, DataLoader epoch, train  (8f-1)
 """
 import argparse
+import copy
 import asyncio
 import os
 import sys
@@ -779,9 +780,57 @@ def gen_train():
     print("train.npz", len(out), "arrays")
 
 
+# ---------------------------------------------------------------- training-mode residual blocks
+def gen_train_tower():
+    """The reference's own ResBlock modules (nn.py:33-58) under .train(True): forward on a post-ReLU input, backward of a
+    random output gradient -- what csrc/train.hip (dbaz_trainer_*) computes.  Weights are regenerated from the seed in the test
+    (same construction order as oracle/nn_ref._Block; checksum stored), BatchNorm affines / running statistics randomised.
+    Seeds are advanced until no ReLU input of the float64 evaluation lies within 2e-6 of zero (a float32 evaluation may put
+    such an element on the other side and the gradients are then not comparable)."""
+    import nn as ref_nn
+    out = {}
+    torch.set_num_threads(1)
+    for (r, c, nb, n, tag) in ((3, 3, 1, 6, "t33"), (6, 6, 2, 5, "t66")):
+        H, W = r + 1, c + 1
+        for seed in range(100, 200):
+            torch.manual_seed(seed)
+            blocks = torch.nn.Sequential(*[ref_nn.ResBlock(64, 3, 1, None) for _ in range(nb)])
+            nn_ref.randomize_bn(blocks, seed + 1)
+            g = torch.Generator().manual_seed(seed + 2)
+            x = torch.relu(torch.randn(n, 64, H, W, generator=g))
+            gout = torch.randn(n, 64, H, W, generator=g) * 1e-2
+            b64 = copy.deepcopy(blocks).double().train(True)
+            margin, xx = float("inf"), x.double()
+            with torch.no_grad():
+                for blk in b64:
+                    pre1 = blk.bn1(blk.conv1(xx))
+                    pre2 = blk.bn2(blk.conv2(torch.relu(pre1))) + xx
+                    margin = min(margin, float(pre1.abs().min()), float(pre2.abs().min()))
+                    xx = torch.relu(pre2)
+            if margin >= 2e-6:
+                break
+        checksum = nn_ref.state_dict_checksum(blocks)
+        blocks.train(True)
+        xr = x.clone().requires_grad_(True)
+        y = blocks(xr)
+        y.backward(gout)
+        out[tag + "_cfg"] = np.array([r, c, nb, n, seed], dtype=np.int32)
+        out[tag + "_checksum"] = np.float64(checksum)
+        out[tag + "_out"] = y.detach().numpy()
+        out[tag + "_grad_x"] = xr.grad.numpy()
+        for k, p_ in blocks.named_parameters():
+            gnp = p_.grad.numpy()
+            out[tag + "_g_" + k] = gnp if gnp.size <= 64 else gnp.ravel()[::37].copy()   # conv gradients: every 37th element
+        for k, v in blocks.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                out[tag + "_s_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "train_tower.npz"), **out)
+    print("train_tower.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="rules,boards,mcts,pending,nn,selfplay,match,train")
+    ap.add_argument("--only", default="rules,boards,mcts,pending,nn,selfplay,match,train,train_tower")
     args = ap.parse_args()
     todo = args.only.split(",")
     if "rules" in todo:
@@ -800,3 +849,5 @@ if __name__ == "__main__":
         gen_match()
     if "train" in todo:
         gen_train()
+    if "train_tower" in todo:
+        gen_train_tower()

@@ -292,3 +292,34 @@ def test_exact_f32_weight_gradient_path(monkeypatch):
     train_tower._trainers.clear()
     for k in ("0.conv1.weight", "0.conv2.weight"):
         assert rel(gr_f32[k], gr64[k]) < 2e-5 and rel(gr_h3[k], gr64[k]) < 2e-5 and rel(gr_f32[k], gr_h3[k]) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["t33", "t66"])
+def test_golden_reference_resblocks_in_training_mode(tag):
+    """tests/golden/train_tower.npz: the REFERENCE's own ResBlock modules (nn.py:33-58) under .train(True), forward + backward in
+    float32 on the CPU (gen_golden.gen_train_tower; seeds chosen so that no ReLU input lies within 2e-6 of zero).  The weights
+    are regenerated here from the stored seed (checksum compared), the HIP tower must reproduce output, input gradient, every
+    parameter gradient (conv weights: every 37th element), running statistics and num_batches_tracked."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_tower.npz"))
+    r, c, nb, n, seed = (int(v) for v in G[tag + "_cfg"])
+    torch.manual_seed(seed)
+    blocks = torch.nn.Sequential(*[nn_ref._Block(64, 3) for _ in range(nb)])
+    nn_ref.randomize_bn(blocks, seed + 1)
+    assert nn_ref.state_dict_checksum(blocks) == float(G[tag + "_checksum"])
+    g = torch.Generator().manual_seed(seed + 2)
+    x = torch.relu(torch.randn(n, 64, r + 1, c + 1, generator=g))
+    gout = torch.randn(n, 64, r + 1, c + 1, generator=g) * 1e-2
+    oh, gxh, grh, sth, nbt = run_hip(blocks, x, gout)
+    assert rel(oh, torch.tensor(G[tag + "_out"]).double()) < 2e-6
+    assert rel(gxh, torch.tensor(G[tag + "_grad_x"]).double()) < 2e-5
+    for k in grh:
+        ref = torch.tensor(G[tag + "_g_" + k]).double()
+        got = grh[k] if ref.numel() == grh[k].numel() else grh[k].reshape(-1)[::37]
+        if k.endswith("conv1.bias") or k.endswith("conv2.bias"):
+            assert float(got.abs().max()) <= 1e-4 * float(grh[k.replace("bias", "weight")].abs().max()) + 1e-12, k  # exactly 0 analytically
+            continue
+        assert rel(got.reshape(ref.shape), ref) < 2e-5, k
+    for k, v in sth.items():
+        assert rel(v, torch.tensor(G[tag + "_s_" + k]).double()) < 2e-6, k
+    assert nbt == [1] * (2 * nb)
