@@ -65,3 +65,34 @@ def test_simple_nn_seeded(golden_nn):
     p, v = nn_ref.predict_sync(m, g["simple_X"])
     assert np.abs(p - g["simple_p"]).max() < TOL
     assert np.abs(v - g["simple_v"]).max() < TOL
+
+
+def test_restated_blocks_in_training_mode_match_reference_goldens():
+    """tests/golden/train_tower.npz (the reference's ResBlock modules under .train(True), gen_golden.gen_train_tower): the
+    restated blocks of oracle/nn_ref.py regenerate the same weights from the seed and reproduce forward and backward bit for
+    bit on the CPU -- they are what the HIP training tower is compared with where no golden exists."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import nn_ref
+    torch.set_num_threads(1)
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_tower.npz"))
+    for tag in ("t33", "t66"):
+        r, c, nb, n, seed = (int(v) for v in G[tag + "_cfg"])
+        torch.manual_seed(seed)
+        blocks = torch.nn.Sequential(*[nn_ref._Block(64, 3) for _ in range(nb)])
+        nn_ref.randomize_bn(blocks, seed + 1)
+        assert nn_ref.state_dict_checksum(blocks) == float(G[tag + "_checksum"])
+        g = torch.Generator().manual_seed(seed + 2)
+        x = torch.relu(torch.randn(n, 64, r + 1, c + 1, generator=g)).requires_grad_(True)
+        gout = torch.randn(n, 64, r + 1, c + 1, generator=g) * 1e-2
+        blocks.train(True)
+        y = blocks(x)
+        y.backward(gout)
+        assert np.array_equal(y.detach().numpy(), G[tag + "_out"]) and np.array_equal(x.grad.numpy(), G[tag + "_grad_x"])
+        for k, p in blocks.named_parameters():
+            gnp = p.grad.numpy()
+            assert np.array_equal(gnp if gnp.size <= 64 else gnp.ravel()[::37], G[tag + "_g_" + k]), k
+        for k, v in blocks.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                assert np.array_equal(v.numpy(), G[tag + "_s_" + k]), k
