@@ -274,3 +274,25 @@ def test_nan_priors_follow_numpy_argmax_order():
         saw_nan |= bool(np.isnan(pri).any())
     assert saw_nan   # odd-depth roots carry the NaN prior themselves
     e.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_reference_csv_best_moves(golden_boards, kind):
+    """test/mcts_tests.py:80-124 through the C ABI: the 34 positions of test/test_boards.csv as 34 concurrent searches of
+    800 reads; root arrays bit-exact vs the oracle, and the reference's assertion (most visited move in `next_moves`) on
+    the rows a deterministic evaluator can decide (tests/test_oracle_mcts.py)."""
+    from dotsboxesaz_amd.engine import Engine
+    from test_oracle_mcts import CSV_BEST_MOVE_ROWS, csv_searches
+    rows = csv_searches(golden_boards, kind)
+    e = Engine(3, 3, len(rows), mcts_num_read=800, evaluator="uniform" if kind else "formula")
+    e.set_positions([mv for _, mv, _, _ in rows])
+    e.set_search_params((1.25, 19652.0), (0.0, 0.0))
+    e.search(800, None)
+    r = e.roots()
+    ok = []
+    for s, (i, _, nxt, vis) in enumerate(rows):
+        assert np.array_equal(r["visits"][s], vis), i
+        if int(np.argmax(r["visits"][s])) in nxt:
+            ok.append(i)
+    assert ok == CSV_BEST_MOVE_ROWS[kind]
+    e.close()
