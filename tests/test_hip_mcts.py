@@ -75,7 +75,8 @@ def test_forced_table_was_hit_in_the_golden_scripts():
 
 
 @pytest.mark.parametrize("rows,cols,n_slots,sims,kind", [(3, 3, 512, 120, 0), (6, 6, 384, 200, 0), (6, 6, 64, 300, 1),
-                                                         (9, 9, 96, 150, 0), (2, 4, 128, 90, 0)])
+                                                         (9, 9, 96, 150, 0), (2, 4, 128, 90, 0),
+                                                         (10, 10, 24, 120, 0), (15, 7, 24, 120, 1)])  # largest boards
 @pytest.mark.parametrize("tt", TT_MODES)
 def test_many_slots_vs_oracle(rows, cols, n_slots, sims, kind, tt):
     """Every slot searches a different position; three searches with tree reuse, noise on the
@@ -83,7 +84,7 @@ def test_many_slots_vs_oracle(rows, cols, n_slots, sims, kind, tt):
     hits = _run_vs_oracle(rows, cols, n_slots, sims, kind, (1.25, 19652), True, n_slots + sims, tt)
     if tt != "force":
         assert hits == 0
-    elif rows * cols < 81:  # (150 reads on a 9x9 board rarely transpose: 200 actions, shallow trees)
+    elif rows * cols < 81:  # (150 reads on a 9x9 or larger board rarely transpose: 200 actions, shallow trees)
         assert hits > 0
 
 

@@ -59,7 +59,8 @@ def test_golden_full_size(golden_nn, tag, rows, cols):
 
 @pytest.mark.parametrize("rows,cols,ch,nb,n", [(6, 6, 64, 3, 1), (6, 6, 64, 3, 3), (6, 6, 64, 3, 4), (6, 6, 64, 3, 5),
                                                (6, 6, 64, 3, 333), (3, 3, 64, 2, 257), (9, 9, 64, 2, 77),
-                                               (4, 2, 32, 2, 50), (6, 6, 128, 1, 19), (1, 1, 16, 1, 9)])
+                                               (4, 2, 32, 2, 50), (6, 6, 128, 1, 19), (1, 1, 16, 1, 9),
+                                               (10, 10, 64, 2, 21), (15, 7, 64, 2, 9)])  # the last two: largest boards
 def test_ragged_batches_vs_torch(rows, cols, ch, nb, n):
     """Batch sizes around the samples-per-workgroup boundary; arbitrary float inputs."""
     torch.manual_seed(rows * 31 + cols + ch + n)

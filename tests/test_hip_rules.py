@@ -111,7 +111,8 @@ def test_reference_csv_positions(engines, golden_boards):
         assert [st["to_play"][s], st["just_played"][s], st["b2c2"][s][0], st["b2c2"][s][1], res[s]] == list(g[k + "meta"])
 
 
-@pytest.mark.parametrize("rows,cols,n", [(3, 3, 2048), (6, 6, 4096), (9, 9, 1024), (2, 5, 512), (7, 1, 300)])
+# (10, 10) and (15, 7): the largest boards the library accepts (DBAZ_MAX_A: 2 (rows + 1)(cols + 1) <= 256)
+@pytest.mark.parametrize("rows,cols,n", [(3, 3, 2048), (6, 6, 4096), (9, 9, 1024), (2, 5, 512), (7, 1, 300), (10, 10, 256), (15, 7, 256)])
 def test_random_playouts_vs_oracle(rows, cols, n):
     """Thousands of concurrent seeded playouts, every ply compared with the C oracle."""
     from dotsboxesaz_amd.engine import Engine

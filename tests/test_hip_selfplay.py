@@ -59,7 +59,8 @@ def test_golden_games_teacher_forced(name, n_slots, tt):
 
 @pytest.mark.parametrize("tt", [True, "force"])
 @pytest.mark.parametrize("rows,cols,n_slots,n_games,sims,reuse", [(3, 3, 64, 200, 40, True), (3, 3, 32, 70, 30, False),
-                                                                  (6, 6, 48, 48, 60, True), (2, 3, 16, 40, 50, True)])
+                                                                  (6, 6, 48, 48, 60, True), (2, 3, 16, 40, 50, True),
+                                                                  (10, 10, 6, 6, 24, True)])  # the last: largest square board
 def test_device_sampled_games_vs_oracle(rows, cols, n_slots, n_games, sims, reuse, tt):
     """Production path: moves sampled on the device (Philox), slots refilled as games end.
     The oracle replays each game teacher-forced with the device's moves; all rows must be
