@@ -18,7 +18,7 @@
 #include "replay.h"
 #include "tree.h"
 
-static std::string g_create_error;
+static thread_local std::string g_create_error; // message of a failed dbaz_create (no handle to keep it in); per thread
 
 struct dbaz_engine {
     dbaz_config cfg;

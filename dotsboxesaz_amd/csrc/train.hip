@@ -62,7 +62,7 @@ struct dbaz_trainer {
     unsigned long long *relu_mask = nullptr; // [L][maxN*HW]: sign bits of A[l+1] (64 channels per row)
 };
 
-static std::string g_train_error;
+static thread_local std::string g_train_error; // message of a failed dbaz_trainer_create / dbaz_bn2d_* call; per thread
 
 static int terr(dbaz_trainer *t, int code, const char *fmt, ...)
 {

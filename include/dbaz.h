@@ -16,7 +16,8 @@
  *   - all pointers are HOST pointers unless the name ends in _dev; the caller
  *     owns every buffer; no torch types, no C++ types;
  *   - a handle is single-threaded; one handle per GPU / rank; no process-global
- *     state (board size is per handle, unlike BoxesState.init_static_fields);
+ *     state (board size is per handle, unlike BoxesState.init_static_fields; the
+ *     message of a call that has no handle -- a failed create -- is kept per thread);
  *   - there is NO CPU fallback: without a HIP device dbaz_create fails.
  *
  * Board geometry: rows x cols boxes, H = rows+1, W = cols+1, A = 2*H*W action
