@@ -548,20 +548,20 @@ def main():
                                     "frac": exp * bps / t_tree / 1e9 / 8000.0, "bytes_per_sim": bps,
                                     "note": "latency-bound pointer chase (one wave per game, ~L dependent node "
                                             "visits per sim); a low HBM fraction is expected (SURVEY 8d)"}
-            pmc = os.path.join(REPO, "profiles", "r02_pmc_tower_16x16x32_two_cout_tiles_3840evals.json")
+            pmc = os.path.join(REPO, "profiles", "r02_pmc_tower_driver_window.json")
             if os.path.exists(pmc) and args.precision == 1 and (args.board, args.channels, args.blocks) == (6, 64, 20):
-                # PMC passes cannot run inside this process: the counters of the same kernel, collected by tools/pmc_bench.sh on
-                # launches of exactly 3 rounds (3 838 evaluations), scaled to the rounds of THIS run's launches
+                # PMC passes cannot run inside this process: the counters of the same kernel over the 20 timed launches of
+                # this very command (tools/pmc_driver_window.sh), per evaluation x this run's evaluations per launch
                 t = json.load(open(pmc))
                 evals = m["nn_evals"] / args.steps
-                rounds = evals / (256.0 * 5)
-                out["roofline"]["traffic"] = t.get("traffic_bytes_per_launch") / 3.0 * rounds
+                out["roofline"]["traffic"] = t["traffic_bytes_per_launch"] / t["evals_per_launch"] * evals
                 out["roofline"]["traffic_note"] = (
-                    "(2*FETCH_SIZE + WRITE_SIZE)*1024 B of the main k_tower launch, measured on 3-round launches "
-                    "(profiles/r02_pmc_tower_16x16x32_two_cout_tiles_3840evals.json: 186.6 MB) and scaled to this run's %.2f rounds; "
-                    "per round the 5.9 MB of packed weights are re-streamed Infinity-Cache -> L2 by each of the 8 XCDs (they exceed "
-                    "the 4 MiB L2), not from HBM; algorithmic bytes per launch = features in + head activations out + weights "
-                    "once = %.1f MB" % (rounds, (evals * (588 + 6272) + 5.9e6) / 1e6))
+                    "(2*FETCH_SIZE + WRITE_SIZE)*1024 B of the main k_tower launch, averaged over the 20 timed launches of "
+                    "`bench.py --steps 20 --warmup 5` under rocprofv3 --pmc (profiles/r02_pmc_tower_driver_window.json: %.1f MB at "
+                    "%.0f evaluations per launch), scaled to this run's %.0f evaluations per launch; per round of 1 280 evaluations the "
+                    "5.9 MB of packed weights are re-streamed Infinity-Cache -> L2 by each of the 8 XCDs (they exceed the 4 MiB L2), "
+                    "not from HBM; algorithmic bytes per launch = features in + head activations out + weights once = %.1f MB"
+                    % (t["traffic_bytes_per_launch"] / 1e6, t["evals_per_launch"], evals, (evals * (588 + 6272) + 5.9e6) / 1e6))
                 out["roofline"]["mfma_busy_frac"] = t.get("mfma_busy_frac")
             else:
                 out["roofline"]["traffic"] = None

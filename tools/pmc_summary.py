@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSVs (one directory per pass) into profiles/<name>.json.
 
-    python tools/pmc_summary.py gpurun_out/pmc3 profiles/r01_pmc_tower.json
+    python tools/pmc_summary.py gpurun_out/pmc3 profiles/r01_pmc_tower.json [--last N]
+
+--last N: only the last N launches of every kernel (the timed window of a bench.py run whose last launches are the timed steps).
 
 Traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB-like units of
 1024 B; on gfx950 FETCH_SIZE reads one half of the bytes of wide coalesced streams, so the read
@@ -14,16 +16,28 @@ import json
 import sys
 
 
-def main(src, dst):
+def main(src, dst, last=0):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     files = sorted(glob.glob(src + "/*/*/*_counter_collection.csv")) + sorted(glob.glob(src + "/*/*_counter_collection.csv"))
     for f in files:
-        for r in csv.DictReader(open(f)):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+        if last > 0:  # the last `last` launches of every (kernel, counter) of this pass
+            seen = collections.Counter()
+            keep = []
+            for r in reversed(rows):
+                key = (r["Kernel_Name"], r["Counter_Name"])
+                seen[key] += 1
+                if seen[key] <= last:
+                    keep.append(r)
+            rows = keep
+        for r in rows:
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     out = {"kernels": {}}
+    if last > 0:
+        out["launches_considered"] = "the last %d launches of every kernel" % last
     for k, v in per.items():
         if k.startswith("__amd"):
             continue
@@ -58,4 +72,4 @@ def main(src, dst):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[3] == "--last" else 0)
