@@ -1,5 +1,6 @@
-"""Full BASELINE sizes through size-independent properties (the oracle cannot follow 8192 games x
-800 sims): rules invariants, tree bookkeeping identities and dataset-row consistency."""
+"""Full BASELINE sizes: size-independent properties over ALL games (rules invariants, tree bookkeeping identities,
+dataset-row consistency -- the oracle cannot follow 8192 games x 800 sims), and, with the noise off and the hash-formula
+evaluator, the rows of a sample of the games replayed search by search with the oracle, bit for bit."""
 import numpy as np
 import pytest
 
@@ -40,6 +41,62 @@ def test_config1_3x3_4096_games_100_sims():
     check_rows(got, 3, 3, 4096)
     # every move consumed min(4*n_valid!, 100) reads (+1 root expansion on the first move of a game)
     assert c["expansions"] >= len(got["z"]) * 4
+    e.close()
+
+
+def test_config1_full_size_rows_vs_oracle_searches():
+    """configs[1] at full size with the noise off (numpy's Dirichlet stream cannot be matched on the device): every 16th
+    of the 4 096 games is replayed by the oracle, teacher-forced with the device's moves -- 100-read searches with tree
+    reuse from a fully loaded engine; visit counts, pi, q and TreeStats of every row bit-identical."""
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(3, 3, 4096, mcts_num_read=100, noise=(0.0, 0.0), evaluator="formula", seed=12)
+    e.selfplay_start(4096, 0)
+    e.run()
+    c = e.counters()
+    assert c["games_finished"] == 4096 and c["error_slots"] == 0 and c["pool_resets"] == 0
+    got = e.fetch_samples()
+    d = O.dims(3, 3)
+    pp = O.selfplay_params(100, noise=(0.0, 0.0), reuse_tree=True)
+    ev = O.Evaluator(0)
+    for gi in range(0, 4096, 16):
+        r = np.nonzero(got["game_idx"] == gi)[0]
+        ref = O.play_game(d, pp, ev, forced_moves=got["played"][r])
+        assert ref["n_rows"] == len(r)
+        assert np.array_equal(ref["visits"], got["visits"][r])
+        assert np.array_equal(ref["pi"].view(np.uint64), got["pi"][r].view(np.uint64))
+        assert np.array_equal(ref["q_value"].view(np.uint32), got["q_value"][r].view(np.uint32))
+        assert np.array_equal(ref["tree_size"], got["tree_size"][r])
+        assert np.array_equal(ref["terminal_count"], got["terminal_count"][r])
+        assert np.array_equal(ref["max_deepness"], got["max_deepness"][r].astype(np.int32))
+        assert np.array_equal(ref["z"], got["z"][r].astype(np.int64))
+    e.close()
+
+
+def test_config2_full_size_rows_vs_oracle_searches():
+    """configs[2] at full size -- 8 192 concurrent 6x6 games, 800 reads per move, tree reuse, complete games -- with the
+    hash-formula evaluator and the noise off: 16 of the games are replayed by the oracle, teacher-forced with the device's
+    moves; every row's visit counts, pi, q and TreeStats bit-identical."""
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(6, 6, 8192, mcts_num_read=800, noise=(0.0, 0.0), evaluator="formula", seed=13)
+    e.selfplay_start(8192, 0)
+    e.run()
+    c = e.counters()
+    assert c["games_finished"] == 8192 and c["error_slots"] == 0 and c["pool_resets"] == 0
+    got = e.fetch_samples()
+    d = O.dims(6, 6)
+    pp = O.selfplay_params(800, noise=(0.0, 0.0), reuse_tree=True)
+    ev = O.Evaluator(0)
+    for gi in range(0, 8192, 512):
+        r = np.nonzero(got["game_idx"] == gi)[0]
+        ref = O.play_game(d, pp, ev, forced_moves=got["played"][r])
+        assert ref["n_rows"] == len(r)
+        assert np.array_equal(ref["visits"], got["visits"][r])
+        assert np.array_equal(ref["pi"].view(np.uint64), got["pi"][r].view(np.uint64))
+        assert np.array_equal(ref["q_value"].view(np.uint32), got["q_value"][r].view(np.uint32))
+        assert np.array_equal(ref["tree_size"], got["tree_size"][r])
+        assert np.array_equal(ref["terminal_count"], got["terminal_count"][r])
+        assert np.array_equal(ref["max_deepness"], got["max_deepness"][r].astype(np.int32))
+        assert np.array_equal(ref["z"], got["z"][r].astype(np.int64))
     e.close()
 
 
@@ -120,6 +177,34 @@ def test_config4_9x9_2048_games_1600_sims_steps():
     assert (r["visits"][~valid] == 0).all() and (r["priors"][~valid] == 0).all()
     assert (r["stats"][:, 0] >= 0).all() and (r["stats"][:, 0] <= e.E + 1).all()          # max_deepness
     assert c["pool_high_water"] <= K + 2 and c["moves_played"] >= moved.sum()
+    e.close()
+
+
+def test_config4_full_size_rows_vs_oracle_searches():
+    """The per-GPU share of configs[4] at full size -- 2 048 concurrent 9x9 games, 1 600 reads per move, 16 020-node pools,
+    complete games -- hash-formula evaluator, noise off: 4 of the games replayed by the oracle, teacher-forced with the
+    device's moves; every row's visit counts, pi, q and TreeStats bit-identical."""
+    from dotsboxesaz_amd.engine import Engine
+    e = Engine(9, 9, 2048, mcts_num_read=1600, noise=(0.0, 0.0), evaluator="formula", seed=14)
+    e.selfplay_start(2048, 0)
+    e.run()
+    c = e.counters()
+    assert c["games_finished"] == 2048 and c["error_slots"] == 0 and c["pool_resets"] == 0
+    got = e.fetch_samples()
+    d = O.dims(9, 9)
+    pp = O.selfplay_params(1600, noise=(0.0, 0.0), reuse_tree=True)
+    ev = O.Evaluator(0)
+    for gi in range(0, 2048, 512):
+        r = np.nonzero(got["game_idx"] == gi)[0]
+        ref = O.play_game(d, pp, ev, forced_moves=got["played"][r])
+        assert ref["n_rows"] == len(r)
+        assert np.array_equal(ref["visits"], got["visits"][r])
+        assert np.array_equal(ref["pi"].view(np.uint64), got["pi"][r].view(np.uint64))
+        assert np.array_equal(ref["q_value"].view(np.uint32), got["q_value"][r].view(np.uint32))
+        assert np.array_equal(ref["tree_size"], got["tree_size"][r])
+        assert np.array_equal(ref["terminal_count"], got["terminal_count"][r])
+        assert np.array_equal(ref["max_deepness"], got["max_deepness"][r].astype(np.int32))
+        assert np.array_equal(ref["z"], got["z"][r].astype(np.int64))
     e.close()
 
 
