@@ -159,6 +159,55 @@ def test_resnet_selfplay_end_to_end():
     e.close()
 
 
+@pytest.mark.parametrize("rows,cols,n_slots,n_games,sims,blocks,precision", [(3, 3, 16, 32, 25, 4, 0), (3, 3, 16, 32, 25, 4, 1),
+                                                                            (6, 6, 8, 3, 40, 20, 1), (6, 6, 2048, 2048, 30, 20, 1)])
+def test_resnet_selfplay_rows_vs_oracle_fed_by_the_hip_network(rows, cols, n_slots, n_games, sims, blocks, precision):
+    """Self-play with the network evaluator, bit for bit: the games the engine played (device-sampled moves, leaves of all
+    games in one batch per step, transposition table on) are replayed by the oracle's sequential search, whose evaluator
+    asks the same engine for (p, v) of one position at a time (predict_sync) -- a sample's result does not depend on its
+    batch (utils/proxies.py:35-43), so every row must come out identical: visits, pi, q, TreeStats, z.  The 2 048-slot case
+    runs whole rounds of the two-cout-tile kernel, the remainder bodies and the full-rounds-only cut (4 of its games are
+    replayed); predict_sync of one position runs the smallest one-cout-tile body."""
+    import torch
+    from oracle import nn_ref
+    from dotsboxesaz_amd.engine import Engine
+    torch.manual_seed(rows * 10 + blocks)
+    m = nn_ref.ResNetZeroRef(rows, cols, 64, blocks)
+    nn_ref.randomize_bn(m, 3)
+    e = Engine(rows, cols, n_slots, mcts_num_read=sims, noise=(0.0, 0.0), evaluator="resnet", seed=5, nn_precision=precision)
+    e.load_state_dict(m.state_dict(), "resnet", 64, blocks, 16, 8)
+    e.selfplay_start(n_games, 0)
+    e.run()
+    cnt = e.counters()
+    assert cnt["games_finished"] == n_games and cnt["error_slots"] == 0 and cnt["cache_hits"] > 0
+    got = e.fetch_samples()
+    d = O.dims(rows, cols)
+    memo = {}
+
+    def hip_net(dd, st):
+        x = O.features(dd, st)
+        key = x.tobytes()
+        if key not in memo:
+            pv = e.predict(x.astype(np.float32).reshape(1, 3, rows + 1, cols + 1))
+            memo[key] = (pv[0][0].copy(), pv[1][0].copy())
+        return memo[key]
+
+    ev = O.Evaluator(hip_net)
+    pp = O.selfplay_params(sims, noise=(0.0, 0.0), reuse_tree=True)
+    for gi in range(0, n_games, 1 if n_games <= 32 else n_games // 4):
+        r = np.nonzero(got["game_idx"] == gi)[0]
+        ref = O.play_game(d, pp, ev, forced_moves=got["played"][r])
+        assert ref["n_rows"] == len(r)
+        assert np.array_equal(ref["visits"], got["visits"][r]), gi
+        assert np.array_equal(ref["pi"].view(np.uint64), got["pi"][r].view(np.uint64))
+        assert np.array_equal(ref["q_value"].view(np.uint32), got["q_value"][r].view(np.uint32))
+        assert np.array_equal(ref["tree_size"], got["tree_size"][r])
+        assert np.array_equal(ref["terminal_count"], got["terminal_count"][r])
+        assert np.array_equal(ref["max_deepness"], got["max_deepness"][r].astype(np.int32))
+        assert np.array_equal(ref["z"], got["z"][r].astype(np.int64))
+    e.close()
+
+
 def test_output_buffer_backpressure():
     """A tiny finished-row buffer: finished games wait (PH_EMIT), run() drains and resumes;
     nothing is lost or duplicated."""
