@@ -3,9 +3,9 @@
 ResNetZero 20x64 (random init, f16x3), complete games with device-sampled moves and the noise off (numpy's Dirichlet stream
 cannot be matched on the device); then K of the games are replayed by the oracle's sequential search (oracle/dbaz_oracle.c),
 teacher-forced with the device's moves, its evaluator asking the same engine for (p, v) of one position at a time.  Every
-row of those games -- visit counts, pi, q, TreeStats, z -- must be identical.  Test infrastructure (uses oracle/), ~3 min:
+row of those games -- visit counts, pi, q, TreeStats, z -- must be identical.  Test infrastructure (uses oracle/; not collected by pytest: ~3 min of GPU time):
 
-    python tools/verify_headline_games.py [K] [slots] [sims]      -> one JSON line"""
+    python tests/verify_headline_games.py [K] [slots] [sims]      -> one JSON line"""
 import json
 import os
 import sys
