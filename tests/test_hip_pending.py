@@ -239,3 +239,61 @@ def test_pending_waves_many_slots_vs_oracle(rows, cols, n_slots, sims, K):
                 trees[s].advance(int(moves[s]), True)
         e.advance(moves, True)
     e.close()
+
+
+@pytest.mark.parametrize("K", [1, 8, 64])
+def test_pending_waves_with_the_network_vs_oracle_fed_by_it(K):
+    """Searches of several 6x6 trees with K simulations in flight and the ResNetZero evaluator (the reference's bookkeeping,
+    virtual_visits = 0), against the oracle's wave search whose evaluator asks the same engine for (p, v) of one position at a
+    time: root arrays and statistics bit-identical, across a re-root with tree reuse."""
+    import torch
+    from oracle import nn_ref
+    from dotsboxesaz_amd.engine import Engine
+    rows = cols = 6
+    d = O.dims(rows, cols)
+    rng = np.random.RandomState(40 + K)
+    n_slots, sims = 6, 160
+    starts = _starts(d, n_slots, rng)
+    torch.manual_seed(K)
+    m = nn_ref.ResNetZeroRef(rows, cols, 64, 6)
+    nn_ref.randomize_bn(m, 3)
+    e = Engine(rows, cols, n_slots, mcts_num_read=sims, evaluator="resnet", nn_precision=1, max_pending_evals=max(K, 2))
+    e.load_state_dict(m.state_dict(), "resnet", 64, 6, 16, 8)
+    e.set_pending(K, virtual_visits=False)
+    e.set_positions(starts)
+    memo = {}
+
+    def hip_net(dd, st):
+        x = O.features(dd, st)
+        key = x.tobytes()
+        if key not in memo:
+            pv = e.predict(x.astype(np.float32).reshape(1, 3, rows + 1, cols + 1))
+            memo[key] = (pv[0][0].copy(), pv[1][0].copy())
+        return memo[key]
+
+    ev = O.Evaluator(hip_net)
+    trees = [O.Tree(d, O.state_from_moves(d, mv)) for mv in starts]
+    reads = rng.randint(sims // 2, sims + 1, size=n_slots).astype(np.int32)
+    for rnd in range(2):
+        e.set_search_params((1.25, 19652), (0.0, 0.0))
+        e.search(reads, None)
+        r = e.roots()
+        moves = np.zeros(n_slots, np.int32)
+        for s in range(n_slots):
+            vis = trees[s].search(int(reads[s]), ev, dirichlet=(0.0, 0.0), noise=None, max_pending=K)
+            pri, tv, nv, pc = trees[s].root_arrays()
+            assert np.array_equal(r["visits"][s], vis), (rnd, s)
+            assert np.array_equal(r["total_value"][s].view(np.uint32), tv.view(np.uint32)), (rnd, s)
+            assert np.array_equal(r["priors"][s].view(np.uint64), pri.view(np.uint64)), (rnd, s)
+            md, ts, tc, q = trees[s].stats()
+            assert list(r["stats"][s]) == [md, ts, tc] and r["q"][s].view(np.uint32) == np.float32(q).view(np.uint32)
+            moves[s] = int(np.argmax(vis))
+        for s in range(n_slots):
+            tmp = trees[s].state
+            O.play_(d, tmp, int(moves[s]))
+            if O.get_result(tmp) is not None:
+                moves[s] = -1
+            else:
+                trees[s].advance(int(moves[s]), True)
+        e.advance(moves, True)
+    e.close()
