@@ -109,13 +109,36 @@ def cpu_baseline(rows, cols, sims, budget_s, channels, blocks, max_procs=64):
                        % (rows, cols, sims, procs, blocks, channels, budget_s, total, wall))
 
 
+PMC_TOWER_PROFILE = os.path.join(REPO, "profiles", "r03_pmc_tower_driver_window.json")
+
+
+def tower_traffic(profile_path, lib_nn_hash, evals_per_launch):
+    """roofline.traffic of the main k_tower launch from the committed PMC summary (tools/pmc_driver_window.sh; PMC passes cannot run
+    inside this process) -- but only when that summary was measured on the build of the network kernels that is loaded now: the
+    summary stores dbaz_build_info()'s nn= hash of the library it ran on.  Returns (traffic or None, note, mfma_busy_frac or None)."""
+    if not os.path.exists(profile_path):
+        return None, "no PMC summary at %s" % os.path.relpath(profile_path, REPO), None
+    t = json.load(open(profile_path))
+    have = (t.get("build") or {}).get("nn")
+    if not have or have != lib_nn_hash:
+        return None, ("traffic withheld: %s was measured on network kernels nn=%s, the loaded library is nn=%s -- rerun "
+                      "tools/pmc_driver_window.sh on this build" % (os.path.relpath(profile_path, REPO), have, lib_nn_hash)), None
+    per_eval = t["traffic_bytes_per_launch"] / t["evals_per_launch"]
+    note = ("(2*FETCH_SIZE + WRITE_SIZE)*1024 B of the main k_tower launch, averaged over the timed launches of `bench.py --steps %s "
+            "--warmup %s` under rocprofv3 --pmc (%s, same build nn=%s: %.1f MB at %.0f evaluations per launch), scaled to this run's "
+            "%.0f evaluations per launch; algorithmic bytes per launch = features in + head activations out + weights once = %.1f MB"
+            % (t.get("steps", "?"), t.get("warmup", "?"), os.path.relpath(profile_path, REPO), have, t["traffic_bytes_per_launch"] / 1e6,
+               t["evals_per_launch"], evals_per_launch, (evals_per_launch * (588 + 6272) + 5.9e6) / 1e6))
+    return per_eval * evals_per_launch, note, t.get("mfma_busy_frac")
+
+
 def make_engine(args, precision, rank, local_rank, torch, slots=None):
     from dotsboxesaz_amd.engine import Engine
     from dotsboxesaz_amd import nn as dnn
     rows = cols = args.board
     eng = Engine(rows, cols, slots or args.slots, mcts_num_read=args.sims, noise=(0.8, 0.25), reuse_tree=True,
                  evaluator=args.evaluator, seed=1000 + rank, device=local_rank, nn_precision=precision,
-                 nodes_per_slot=args.nodes_per_slot, transposition_cache=not args.no_tt)
+                 nodes_per_slot=args.nodes_per_slot, transposition_cache=not args.no_tt, debug_flags=args.debug_flags)
     if args.evaluator == "resnet":
         torch.manual_seed(0)
         model = dnn.ResNetZero(dnn.resnet_params(rows, cols, args.channels, args.blocks))
@@ -182,7 +205,8 @@ def run_engine(args, precision, steps, warmup, rank, local_rank, world, dist, to
     c1 = eng.counters()
     if c1["error_slots"]:
         raise SystemExit("engine reported %d slots in error (node pool exhausted?)" % c1["error_slots"])
-    m = {k: c1[k] - c0[k] for k in ("expansions", "nn_evals", "sum_path", "terminal_leaves", "moves_played", "cache_hits")}
+    m = {k: c1[k] - c0[k] for k in ("expansions", "nn_evals", "sum_path", "terminal_leaves", "moves_played", "cache_hits",
+                                    "f32_fallback_evals", "pool_resets")}
     m.update(dt=dt, ms_total=c1["ms_total"], ms_nn_tower=c1["ms_nn_tower"], pool_high_water=c1["pool_high_water"],
              nodes_per_slot=eng.nodes_per_slot, E=eng.E, prep_steps=prep)
     if dist is not None:
@@ -227,7 +251,9 @@ def play_complete_games(args, n_games, slots, rank, local_rank, torch, budget_s=
            "mean_path_len": c["sum_path"] / max(1, c["expansions"]),
            "terminal_leaf_fraction": c["terminal_leaves"] / max(1, c["expansions"]),
            "cache_hit_fraction": c["cache_hits"] / max(1, c["expansions"]),
-           "pool_high_water": c["pool_high_water"], "pool_resets": c["pool_resets"], "steps": c["steps"]}
+           "pool_high_water": c["pool_high_water"], "pool_resets": c["pool_resets"], "steps": c["steps"],
+           "nn_evals": c["nn_evals"], "f32_fallback_evals": c["f32_fallback_evals"],
+           "f32_fallback_fraction": c["f32_fallback_evals"] / max(1, c["nn_evals"])}
     eng.close()
     return out
 
@@ -405,8 +431,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "simplenn", "formula", "uniform"])
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2, 3, 4],
-                    help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default); 2 = the same arithmetic on "
-                         "the 32x32x16 MFMA tiling (DESIGN.md 5.1: measured, not faster)")
+                    help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default); 2 / 3 / 4 = A/B tilings of the "
+                         "f16x3 layer, debug build only (DBAZ_LIB=dotsboxesaz_amd/libdbaz_hip_debug.so; EXPERIMENTS.md)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="dbaz_config.debug_flags (1 = early join, 2 = no f32 fallback launch)")
     ap.add_argument("--nodes-per-slot", type=int, default=0, help="tree node pool per game (0 = engine default 10*(sims+2))")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -520,8 +547,12 @@ def main():
             "mean_path_len": spath / max(1, exp), "terminal_leaf_fraction": term / max(1, exp),
             "cache_hit_fraction": m["cache_hits"] / max(1, exp),
             "pool_high_water": m["pool_high_water"], "nodes_per_slot": m["nodes_per_slot"],
-            "moves_played": m["moves_played"],
+            "moves_played": m["moves_played"], "pool_resets": m["pool_resets"],
+            # nn_precision = 1: evaluations whose activations left f16's range and were redone by the exact-f32 tower (timed steps)
+            "f32_fallback_evals": m["f32_fallback_evals"], "f32_fallback_fraction": m["f32_fallback_evals"] / max(1, m["nn_evals"]),
         }
+        from dotsboxesaz_amd import _lib as _dl
+        out["build"] = _dl.build_info()
         # games/s: expansions/s divided by the measured mean expansions of a full game
         # (DESIGN.md "Measurement"; 6x6 @ 800 sims: 63.2k)
         out["population"] = {"games": "mid-game positions reached by quick play (%d reads per move), staggered full searches, %d "
@@ -548,21 +579,12 @@ def main():
                                     "frac": exp * bps / t_tree / 1e9 / 8000.0, "bytes_per_sim": bps,
                                     "note": "latency-bound pointer chase (one wave per game, ~L dependent node "
                                             "visits per sim); a low HBM fraction is expected (SURVEY 8d)"}
-            pmc = os.path.join(REPO, "profiles", "r02_pmc_tower_driver_window.json")
-            if os.path.exists(pmc) and args.precision == 1 and (args.board, args.channels, args.blocks) == (6, 64, 20):
-                # PMC passes cannot run inside this process: the counters of the same kernel over the 20 timed launches of
-                # this very command (tools/pmc_driver_window.sh), per evaluation x this run's evaluations per launch
-                t = json.load(open(pmc))
-                evals = m["nn_evals"] / args.steps
-                out["roofline"]["traffic"] = t["traffic_bytes_per_launch"] / t["evals_per_launch"] * evals
-                out["roofline"]["traffic_note"] = (
-                    "(2*FETCH_SIZE + WRITE_SIZE)*1024 B of the main k_tower launch, averaged over the 20 timed launches of "
-                    "`bench.py --steps 20 --warmup 5` under rocprofv3 --pmc (profiles/r02_pmc_tower_driver_window.json: %.1f MB at "
-                    "%.0f evaluations per launch), scaled to this run's %.0f evaluations per launch; per round of 1 280 evaluations the "
-                    "5.9 MB of packed weights are re-streamed Infinity-Cache -> L2 by each of the 8 XCDs (they exceed the 4 MiB L2), "
-                    "not from HBM; algorithmic bytes per launch = features in + head activations out + weights once = %.1f MB"
-                    % (t["traffic_bytes_per_launch"] / 1e6, t["evals_per_launch"], evals, (evals * (588 + 6272) + 5.9e6) / 1e6))
-                out["roofline"]["mfma_busy_frac"] = t.get("mfma_busy_frac")
+            if args.precision == 1 and (args.board, args.channels, args.blocks) == (6, 64, 20):
+                tr, note, busy = tower_traffic(PMC_TOWER_PROFILE, out["build"].get("nn"), m["nn_evals"] / args.steps)
+                out["roofline"]["traffic"] = tr
+                out["roofline"]["traffic_note"] = note
+                if busy is not None:
+                    out["roofline"]["mfma_busy_frac"] = busy
             else:
                 out["roofline"]["traffic"] = None
         else:

@@ -13,10 +13,12 @@ LIB_PATH = os.environ.get("DBAZ_LIB") or os.path.join(_HERE, "libdbaz_hip.so")  
 OK, EINVAL, EILLEGAL, EDEVICE, EPOOL, ESTATE = range(6)
 RESULT_NONE = 2
 EVAL_FORMULA_HASH, EVAL_FORMULA_UNIFORM, EVAL_RESNET, EVAL_SIMPLENN, EVAL_EXTERNAL = range(5)
+ABI_VERSION = 3  # DBAZ_ABI_VERSION of include/dbaz.h
+DBG_EARLY_JOIN, DBG_NO_FALLBACK = 1, 2
 
 # every symbol include/dbaz.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "dbaz_last_error", "dbaz_version", "dbaz_nodes_per_slot", "dbaz_create", "dbaz_destroy", "dbaz_sync",
+    "dbaz_last_error", "dbaz_version", "dbaz_build_info", "dbaz_nodes_per_slot", "dbaz_create", "dbaz_destroy", "dbaz_sync",
     "dbaz_rules_init", "dbaz_rules_valid_moves", "dbaz_rules_play", "dbaz_rules_result", "dbaz_rules_features",
     "dbaz_nn_configure", "dbaz_nn_select_model", "dbaz_nn_set_tensor", "dbaz_nn_commit", "dbaz_nn_predict",
     "dbaz_set_search_params", "dbaz_set_positions", "dbaz_search", "dbaz_search_timed", "dbaz_set_pending", "dbaz_search_begin", "dbaz_select", "dbaz_expand_backup",
@@ -38,7 +40,8 @@ class Config(C.Structure):
         ("n_temp", C.c_int32), ("temp_idx", C.c_int32 * 8), ("temp_val", C.c_double * 8),
         ("evaluator", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64), ("max_out_rows", C.c_int32),
         ("nn_precision", C.c_int32), ("match_play", C.c_int32), ("evaluator2", C.c_int32),
-        ("transposition_cache", C.c_int32), ("max_pending_evals", C.c_int32),
+        ("transposition_cache", C.c_int32), ("max_pending_evals", C.c_int32), ("selfplay_pending", C.c_int32),
+        ("eval_round", C.c_int32), ("eval_defer_max", C.c_int32), ("debug_flags", C.c_uint32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -78,11 +81,16 @@ def load():
     except Exception:
         pass
     L = C.CDLL(LIB_PATH)
+    L.dbaz_version.restype = C.c_int
+    if L.dbaz_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, this binding expects %d: rebuild with `python -m dotsboxesaz_amd.build`"
+                          % (LIB_PATH, L.dbaz_version(), ABI_VERSION))
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.dbaz_last_error.argtypes = [vp]
     L.dbaz_last_error.restype = C.c_char_p
     L.dbaz_version.restype = C.c_int
     L.dbaz_nodes_per_slot.argtypes = [vp]
+    L.dbaz_build_info.restype = C.c_char_p
     L.dbaz_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.dbaz_destroy.argtypes = [vp]
     L.dbaz_destroy.restype = None
@@ -132,11 +140,17 @@ def load():
     L.dbaz_bn2d_backward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("dbaz_last_error", "dbaz_destroy", "dbaz_trainer_last_error", "dbaz_trainer_destroy", "dbaz_bn2d_workspace_bytes"):
+        if name not in ("dbaz_last_error", "dbaz_build_info", "dbaz_destroy", "dbaz_trainer_last_error", "dbaz_trainer_destroy", "dbaz_bn2d_workspace_bytes"):
             fn.restype = C.c_int
     L.dbaz_bn2d_workspace_bytes.restype = C.c_int64
     _lib = L
     return L
+
+
+def build_info():
+    """{"src": hash of all kernel sources, "nn": hash of the network kernels} of the LOADED library (csrc/buildinfo.cpp)."""
+    info = load().dbaz_build_info().decode()
+    return dict(kv.split("=", 1) for kv in info.split() if "=" in kv)
 
 
 def check(handle, rc):

@@ -76,7 +76,9 @@ class Coach:
         if self.dist is not None and world > 1:
             rows, _ = sp.all_gather_rows(rows, self.dist)
         self.store.add_generation(generation, rows, train_split=float(_get(_get(_get(self.params, "nn"), "train_params"), "train_split", 0.9)))
-        return dict(rows=int(rows.shape[0]), seconds=time.time() - tick, games=n_games)
+        c = e.counters()  # this rank's games: network evaluations, those the exact-f32 safety net redid, tree-reuse fallbacks
+        return dict(rows=int(rows.shape[0]), seconds=time.time() - tick, games=n_games, nn_evals=int(c["nn_evals"]),
+                    f32_fallback_evals=int(c["f32_fallback_evals"]), pool_resets=int(c["pool_resets"]), moves_played=int(c["moves_played"]))
 
     def train_nn(self, generation, writer=None):
         """coach.train_nn (coach.py:35-96) on the device-resident window."""

@@ -87,7 +87,7 @@ static int set_error(dbaz_engine *e, int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *dbaz_last_error(const dbaz_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
-extern "C" int dbaz_version(void) { return 1; }
+extern "C" int dbaz_version(void) { return DBAZ_ABI_VERSION; }
 extern "C" int dbaz_nodes_per_slot(const dbaz_engine *e) { return e ? e->g.cap : 0; }
 #ifdef DBAZ_STAMP
 // diagnostic builds (tools/stamp_build_run.sh) only: the shipped library does not export it, include/dbaz.h does not declare it
@@ -178,6 +178,12 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     if (cfg->max_pending_evals < 0 || cfg->max_pending_evals > 1024) return set_error(nullptr, DBAZ_EINVAL, "max_pending_evals must be in 0..1024");
     if (cfg->max_pending_evals > 1 && (cfg->evaluator == DBAZ_EVAL_EXTERNAL || cfg->match_play))
         return set_error(nullptr, DBAZ_EINVAL, "max_pending_evals > 1 needs a device evaluator and no match play");
+#ifdef DBAZ_DEBUG
+    if (cfg->nn_precision < 0 || cfg->nn_precision > 4) return set_error(nullptr, DBAZ_EINVAL, "nn_precision must be in 0..4 (debug build)");
+#else
+    if (cfg->nn_precision < 0 || cfg->nn_precision > 1) return set_error(nullptr, DBAZ_EINVAL, "nn_precision must be 0 (exact f32) or 1 (f16x3)");
+#endif
+    if (cfg->eval_round < -1 || cfg->eval_defer_max < 0) return set_error(nullptr, DBAZ_EINVAL, "bad eval_round / eval_defer_max");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -217,10 +223,12 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     if (cfg->nodes_per_slot > 0) {
         g.cap = cfg->nodes_per_slot;
     } else {
-        // default: 10 searches' worth of nodes; up to 40 where all pools together stay within a third of the HBM (a trained
-        // network keeps most of its tree from move to move: dbaz_counters.pool_resets)
+        // default: 10 searches' worth of nodes; up to 40 where all pools together stay within a third of the device's memory
+        // (a trained network keeps most of its tree from move to move: dbaz_counters.pool_resets)
         const long long base = 10LL * (cfg->mcts_num_read + 2), wide = 4 * base;
-        const long long fit = (96LL << 30) / ((long long)cfg->n_slots * g.node_dw * 4);
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || mem_total == 0) mem_total = (size_t)288 << 30;
+        const long long fit = (long long)(mem_total / 3) / ((long long)cfg->n_slots * g.node_dw * 4);
         g.cap = (int)std::min(wide, std::max(base, fit));
     }
     if (g.cap < 8) g.cap = 8;
@@ -317,14 +325,14 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     }
     B.first_game = 0;
     B.last_game = 0;
-    e->nns[0] = nn_create(g, e->n_slots * B.kmax, cfg->nn_precision);
-    e->nns[1] = nn_create(g, e->n_slots, cfg->nn_precision);
+    e->nns[0] = nn_create(g, e->n_slots * B.kmax, cfg->nn_precision, (cfg->debug_flags & DBAZ_DBG_NO_FALLBACK) != 0);
+    e->nns[1] = nn_create(g, e->n_slots, cfg->nn_precision, (cfg->debug_flags & DBAZ_DBG_NO_FALLBACK) != 0);
     e->nn = e->nns[0];
     CREATE_HIP(hipStreamSynchronize(e->stream));
     // every slot starts as an idle empty board
     tree_launch_set_positions(e->stream, g, sc, B, e->n_slots, nullptr, nullptr);
     CREATE_HIP(hipStreamSynchronize(e->stream));
-    e->late_join = getenv("DBAZ_EARLY_JOIN") == nullptr; // (DBAZ_EARLY_JOIN: measurement aid, joins in front of the network as round 2 did at first)
+    e->late_join = (cfg->debug_flags & DBAZ_DBG_EARLY_JOIN) == 0;
     *out = e;
     return DBAZ_OK;
 }
@@ -481,11 +489,12 @@ extern "C" int dbaz_nn_commit(dbaz_engine *e)
     HIP_CHECK_RET(e, hipStreamSynchronize(e->stream));
     if (e->nn == e->nns[0]) {
         nn_round_info(e->nn, &e->eval_round, &e->eval_defer_max);
-        // measurement / test aids: DBAZ_EVAL_ROUND=0 switches the cut off, =r[,d] forces a round size (and the largest left-over
+        // dbaz_config.eval_round: -1 switches the cut off, r > 0 forces a round size (and eval_defer_max the largest left-over
         // that is put off) so that small test runs go through the same path
-        if (const char *v = getenv("DBAZ_EVAL_ROUND")) {
-            int rr = 0, dd = -1;
-            if (sscanf(v, "%d,%d", &rr, &dd) >= 1) { e->eval_round = rr; e->eval_defer_max = dd >= 0 ? dd : rr - 1; }
+        if (e->cfg.eval_round < 0) e->eval_round = 0;
+        else if (e->cfg.eval_round > 0) {
+            e->eval_round = e->cfg.eval_round;
+            e->eval_defer_max = e->cfg.eval_defer_max > 0 ? e->cfg.eval_defer_max : e->cfg.eval_round - 1;
         }
         if (e->eval_defer_max <= 0) e->eval_round = 0;
     }

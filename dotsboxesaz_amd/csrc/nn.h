@@ -7,7 +7,7 @@
 
 struct NNState;
 
-NNState *nn_create(const Geo &g, int max_batch, int precision);
+NNState *nn_create(const Geo &g, int max_batch, int precision, bool no_fallback = false);
 void nn_destroy(NNState *nn);
 int nn_configure(NNState *nn, int kind, int channels, int blocks, int head_channels, int value_fc, std::string &err);
 int nn_set_tensor(NNState *nn, const char *key, const float *data, int64_t numel, std::string &err);

@@ -87,6 +87,7 @@ struct NNState {
     // f16x3 on 16x16x32 with two cout tiles per wave (k_tower<64, NT, 0, 1, 2>, 64 channels): 4 tile groups of NT_c2 tiles
     int want_c2 = 0, c2 = 0, S_c2 = 0, NT_c2 = 0; // (its remainder goes to the one-cout-tile kernels)
     int use_rem = 0; // f16x3, NTT == 7: the remainder sizes live in ONE launch (k_tower_rem)
+    bool no_fallback = false; // dbaz_config.debug_flags & DBAZ_DBG_NO_FALLBACK (timing runs only)
     size_t conv_lds_c2 = 0;
 };
 
@@ -540,6 +541,7 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
 #endif
 }
 
+#ifdef DBAZ_DEBUG // A/B tiling of the debug build (tools/ab_tilings.sh); measured 2.4 % slower per evaluation (EXPERIMENTS.md)
 // ------------------------------------------------------------------------------------
 // The same f16x3 layer on v_mfma_f32_32x32x16_f16 (MF = 1).  Output tile = 32 couts x 32 positions: a wave owns one
 // 32-cout tile (wave & 1) and NTT position tiles of 32 rows (tile group wave >> 1); per K=16 step it needs ONE weight
@@ -708,6 +710,8 @@ __device__ __forceinline__ void conv_lds_h3_32(const f32x4 *__restrict__ src4, f
     }
     ovf_out |= ovf;
 }
+
+#endif // DBAZ_DEBUG
 
 // ------------------------------------------------------------------------------------
 // The whole convolutional trunk in ONE launch per step.  A workgroup owns S samples; their
@@ -987,7 +991,9 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         (void)pre2;
         if (NL > 0) {
             if constexpr (MF == 2) wpre_load_c2<C>(pre2, tw4, wave, lane);
+#ifdef DBAZ_DEBUG
             else if constexpr (MF == 1) wpre_load32<C>(pre, tw4, wave, lane);
+#endif
             else wpre_load<C>(pre, tw4, wave, lane);
         }
         unsigned long long stamps[4] = {0, 0, 0, 0};
@@ -1001,11 +1007,13 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             const f32x4 *nxt = l + 1 < NL ? tw4 + (size_t)(l + 1) * wl : nullptr;
             if constexpr (MF == 2) {
                 conv_lds_h3_c2<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre2, nxt, stamps);
+#ifdef DBAZ_DEBUG
             } else if constexpr (MF && NTB > 0) {
                 if (first) conv_lds_h3_32<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
                 else conv_lds_h3_32<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
             } else if constexpr (MF) {
                 conv_lds_h3_32<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
+#endif
             } else {
                 if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
                 else if constexpr (NTB > 0) conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
@@ -1564,17 +1572,21 @@ static T *nn_upload(NNState *nn, const std::vector<T> &h)
     return d;
 }
 
-NNState *nn_create(const Geo &g, int max_batch, int precision)
+NNState *nn_create(const Geo &g, int max_batch, int precision, bool no_fallback)
 {
     NNState *nn = new NNState();
     nn->g = g;
     nn->max_batch = max_batch;
-    nn->precision = precision == 2 ? 1 : precision; // 2 = the f16x3 arithmetic of 1 on the 32x32x16 MFMA tiling
+    nn->no_fallback = no_fallback;
+    nn->precision = precision >= 1 ? 1 : 0;
+    // 1 = f16x3 on the default tiling (two cout tiles per wave for 64-channel networks, one otherwise)
+    nn->want_c2 = precision == 1;
+#ifdef DBAZ_DEBUG
+    // A/B tilings (debug build): 2 = the arithmetic of 1 on the 32x32x16 MFMA; 3 / 4 = two / one cout tile(s) per wave explicitly
+    // (1, 3 and 4 give bit-identical results)
     nn->want_mf32 = precision == 2;
-    // 1 = f16x3 on the default tiling (two cout tiles per wave for 64-channel networks, one otherwise), 3 = the former and
-    // 4 = the latter explicitly (A/B measurements; the three give bit-identical results)
     nn->want_c2 = precision == 1 || precision == 3;
-    if (precision == 3 || precision == 4) nn->precision = 1;
+#endif
     return nn;
 }
 
@@ -1744,6 +1756,7 @@ static hipError_t tower_inst(NNState *nn, hipStream_t s, const TowerArgs &ta, in
     hipLaunchKernelGGL((k_tower<C, NTA, NTB, 0>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
     return hipSuccess;
 }
+#ifdef DBAZ_DEBUG
 // the f16x3 tower on the 32x32x16 tiling: nt2 position tiles of 32 rows per wave (8 waves = 2 cout tiles x 4 tile groups)
 template <int C>
 static hipError_t tower_inst_mf(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt2, int grid, bool attr_only)
@@ -1762,6 +1775,7 @@ static hipError_t tower_inst_mf(NNState *nn, hipStream_t s, const TowerArgs &ta,
         return hipErrorInvalidValue;
     }
 }
+#endif
 // the remainder launch (f16x3, geometries whose main one-cout-tile instantiation is <7,6>)
 static hipError_t tower_dispatch_rem(NNState *nn, hipStream_t s, const TowerArgs &ta, int grid, bool attr_only)
 {
@@ -1791,12 +1805,17 @@ static hipError_t tower_dispatch_c2(NNState *nn, hipStream_t s, const TowerArgs 
     }
 #undef C2_CASE
 }
+#ifdef DBAZ_DEBUG
 static hipError_t tower_dispatch_mf(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt2, int grid, bool attr_only)
 {
     if (nn->C == 64) return tower_inst_mf<64>(nn, s, ta, nt2, grid, attr_only);
     if (nn->C == 128) return tower_inst_mf<128>(nn, s, ta, nt2, grid, attr_only);
     return hipErrorInvalidValue;
 }
+
+#else
+static hipError_t tower_dispatch_mf(NNState *, hipStream_t, const TowerArgs &, int, int, bool) { return hipErrorInvalidValue; }
+#endif
 
 template <int C>
 static hipError_t tower_inst_c(NNState *nn, hipStream_t s, const TowerArgs &ta, int ntt, int grid, bool attr_only, int prec)
@@ -2166,7 +2185,7 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             nn->cus = cus;
     }
-    // 32x32x16 tiling (experimental switch DBAZ_MF32): 8 position tiles of 32 rows per workgroup, rows of C + 4 dwords
+    // 32x32x16 tiling (debug build, nn_precision = 2): 8 position tiles of 32 rows per workgroup, rows of C + 4 dwords
     if (nn->mf32 && (C == 64 || C == 128)) {
         auto lds_mf = [&](int S_) {
             const size_t s4 = (C + 4) / 4;
@@ -2300,8 +2319,7 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     }
     }
     }
-    static const bool no_fb = getenv("DBAZ_NO_FALLBACK") != nullptr; // measurement aid only
-    if (nn->precision == 1 && nn->tw32 && !no_fb) {
+    if (nn->precision == 1 && nn->tw32 && !nn->no_fallback) {
         // safety net of the f16x3 mode: samples whose workgroup saw an activation leave f16's range are redone by the
         // exact-f32 tower (its workgroups check the per-sample flags on the device and leave at once otherwise)
         ta.role = 0; ta.S = ta.S_main = nn->S; ta.S_small = ta.S_mid = ta.S_big = ta.S_huge = 0; ta.fallback = 1;

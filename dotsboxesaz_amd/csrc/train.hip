@@ -969,7 +969,10 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
         t->Swh = 1;
         while ((t->Swh + 1) * t->HW <= 208 && wh_lds_bytes(t->Swh + 1, t->H, t->W) <= 150 * 1024) t->Swh++;
         t->wgrad_h3_lds = wh_lds_bytes(t->Swh, t->H, t->W);
-        t->wgrad_h3 = getenv("DBAZ_TRAIN_WGRAD_F32") ? 0 : 1;
+        t->wgrad_h3 = 1;
+#ifdef DBAZ_DEBUG
+        if (getenv("DBAZ_TRAIN_WGRAD_F32")) t->wgrad_h3 = 0; // debug build: the exact-f32 weight gradient kernel (A/B reference)
+#endif
     }
     const size_t ae = act_elems(t);
     hipError_t e = hipSuccess;

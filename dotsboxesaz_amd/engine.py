@@ -22,7 +22,7 @@ class Engine:
     Parameters mirror the reference's configuration (configuration.py:82-100):
     mcts_num_read, cpuct=(c, base), noise=(alpha, coeff), temperature={ply: T},
     reuse_tree.  `evaluator` is one of "formula", "uniform", "resnet", "simplenn",
-    "external".
+    "external".  nn_precision: None = 1 (f16x3 split MFMA, f32-grade) for "resnet", 0 (exact f32 MFMA) otherwise.
     """
 
     EVALUATORS = {"formula": _lib.EVAL_FORMULA_HASH, "uniform": _lib.EVAL_FORMULA_UNIFORM,
@@ -30,8 +30,8 @@ class Engine:
 
     def __init__(self, rows, cols, n_slots, mcts_num_read=800, cpuct=(1.25, 19652), noise=(0.0, 0.0),
                  temperature=None, reuse_tree=True, evaluator="formula", nodes_per_slot=0, seed=0, device=0,
-                 max_out_rows=0, nn_precision=0, match_play=False, evaluator2="formula", transposition_cache=True,
-                 max_pending_evals=1):
+                 max_out_rows=0, nn_precision=None, match_play=False, evaluator2="formula", transposition_cache=True,
+                 max_pending_evals=1, selfplay_pending=False, eval_round=0, eval_defer_max=0, debug_flags=0):
         self._L = _lib.load()
         self.rows, self.cols = int(rows), int(cols)
         self.H, self.W = self.rows + 1, self.cols + 1
@@ -51,12 +51,21 @@ class Engine:
             cfg.temp_idx[i], cfg.temp_val[i] = k, v
         cfg.evaluator = self.EVALUATORS[evaluator] if isinstance(evaluator, str) else int(evaluator)
         cfg.device, cfg.seed, cfg.max_out_rows = int(device), int(seed), int(max_out_rows)
+        # None: the advertised mode of the network -- f16x3 (f32-grade, exact-f32 safety net on the device) for ResNetZero, exact f32
+        # for SimpleNN (whose f16x3 path has no safety net) and the formula evaluators
+        if nn_precision is None:
+            nn_precision = 1 if cfg.evaluator == _lib.EVAL_RESNET else 0
         cfg.nn_precision = int(nn_precision)
         cfg.match_play = int(bool(match_play))
         cfg.evaluator2 = self.EVALUATORS[evaluator2] if isinstance(evaluator2, str) else int(evaluator2)
         # True: on for network evaluators; False: off; "force": on for the formula evaluators too (parity tests)
         cfg.transposition_cache = 2 if transposition_cache == "force" else (0 if transposition_cache else 1)
         cfg.max_pending_evals = int(max_pending_evals)
+        # self-play searches in waves of max_pending_evals simulations per game (self_play.py:27-30's max_async_searches)
+        cfg.selfplay_pending = int(bool(selfplay_pending))
+        # "full rounds only": 0 = the network's own round, -1 = off, r > 0 = rounds of r leaves (tests)
+        cfg.eval_round, cfg.eval_defer_max = int(eval_round), int(eval_defer_max)
+        cfg.debug_flags = int(debug_flags)
         self.cfg = cfg
         self._drained = []
         self.h = C.c_void_p()

@@ -128,7 +128,7 @@ def resnet_params(rows, cols, channels=64, blocks=20, head_channels=16, value_fc
 class NeuralNetWrapper:
     """Reference: nn.py:145-173 -- predict_sync(X [n,3,H,W]) -> (softmax p [n,A], v [n,1]) numpy float32."""
 
-    def __init__(self, model, params=None, engine=None, rows=None, cols=None, n_slots=4096, device=0):
+    def __init__(self, model, params=None, engine=None, rows=None, cols=None, n_slots=4096, device=0, nn_precision=None):
         from .engine import Engine
         self.params = params
         self.engine = engine
@@ -137,7 +137,7 @@ class NeuralNetWrapper:
             if rows is None:
                 raise ValueError("rows/cols (board size) required when no engine is given")
             self.engine = Engine(rows, cols, n_slots, evaluator=model.kind if model is not None else "resnet",
-                                 device=device)
+                                 device=device, nn_precision=nn_precision)
         self.model = None
         if model is not None:
             self.set_model(model)

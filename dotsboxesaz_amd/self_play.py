@@ -106,7 +106,7 @@ def write_dataset(file_name, key, df):
 
 
 def generate_games(hdf_file_name, generation, nn_class, n_games, params, n_workers=None, games_per_workers=10,
-                   rows=None, cols=None, n_slots=None, device=0, dist=None, nn_precision=0):
+                   rows=None, cols=None, n_slots=None, device=0, dist=None, nn_precision=None):
     """Reference: self_play.generate_games (self_play.py:291-306) called from coach.selfplay
     (coach.py:27-29).  Plays n_games with generation-1's weights (random init for generation 0,
     self_play.py:187-190) and appends the samples (+ `training` = 0) to key "fresh".
@@ -114,7 +114,9 @@ def generate_games(hdf_file_name, generation, nn_class, n_games, params, n_worke
     the ranks (the reference's np.array_split over pool workers, :294); every rank keeps its
     finished rows on the device, the packed rows are all-gathered (RCCL; host-staged under gloo)
     and EVERY rank builds the DataFrame of all n_games games -- the reference's workers all append
-    to the one HDF file (self_play.py:264-265); here rank 0 writes it."""
+    to the one HDF file (self_play.py:264-265); here rank 0 writes it.
+    nn_precision: None = the engine's default for the network (ResNetZero: 1, the f16x3 mode every published number of this
+    repository is measured in; 0 = exact f32 MFMA, 2.6x slower)."""
     from .engine import Engine
     game = _get(params, "game")
     if rows is None:
@@ -126,8 +128,8 @@ def generate_games(hdf_file_name, generation, nn_class, n_games, params, n_worke
     model = nn_class(params)
     if generation != 0:
         model.load_parameters(generation - 1)
-    eng = Engine(rows, cols, n_slots, evaluator=model.kind, device=device, seed=generation * 1000003,  # Philox streams are keyed by (seed, game, ply): sharding does not change a game
-                
+    # Philox streams are keyed by (seed, game, ply): sharding does not change a game
+    eng = Engine(rows, cols, n_slots, evaluator=model.kind, device=device, seed=generation * 1000003,
                  nn_precision=nn_precision, **engine_kwargs_from_params(params))
     try:
         if model.kind in ("resnet", "simplenn"):
@@ -298,12 +300,14 @@ def match_winners(samples, generations):
     return n0, n1
 
 
-def compute_elo(elo_params, params, generations, elos, nn_classes=None, rows=None, cols=None, n_slots=None, device=0):
+def compute_elo(elo_params, params, generations, elos, nn_classes=None, rows=None, cols=None, n_slots=None, device=0,
+                nn_precision=None):
     """Reference: self_play.compute_elo(elo_params, [params0, params1], [gen0, gen1], (elo0, elo1)).
     The two models play elo_params.n_games games against each other on the GPU: the model of the
     player to move at the root runs that move's whole search (self_play.py:59,237-239), seats are
     swapped on odd games, the `self_play_override` of elo_params applies (no tree reuse, no noise,
     1200 reads in the shipped configuration, configuration.py:107-113).
+    nn_precision: as in generate_games (None = f16x3 for ResNetZero).
     Returns (elo0, elo1, n1 / number of decided games)."""
     from .engine import Engine
     p0, p1 = params
@@ -328,7 +332,7 @@ def compute_elo(elo_params, params, generations, elos, nn_classes=None, rows=Non
         if gen != 0:
             mdl.load_parameters(gen)  # compare_models: generation g itself (self_play.py:190)
     eng = Engine(rows, cols, n_slots or max(1, min(n_games, 4096)), evaluator=models[0].kind, evaluator2=models[1].kind,
-                 match_play=True, device=device, **kw)
+                 match_play=True, device=device, nn_precision=nn_precision, **kw)
     for i, mdl in enumerate(models):
         eng.load_state_dict(mdl.state_dict(), mdl.kind, model=i, **mdl.shape)
     eng.selfplay_start(n_games, 0)

@@ -33,6 +33,7 @@ class TowerTrainer:
             raise TrainerError(msg.decode() if msg else "dbaz_trainer_create failed (%d)" % rc)
         self.h = h
         self.rows, self.cols, self.channels, self.blocks, self.max_batch, self.device = rows, cols, channels, blocks, max_batch, device
+        self.generation = 0  # id of the forward pass whose activations the handle holds (a handle holds ONE)
 
     def _ck(self, rc):
         if rc != _lib.OK:
@@ -51,18 +52,28 @@ class TowerTrainer:
             pass
 
     def forward(self, x, conv_w, conv_b, bn_w, bn_b, run_mean, run_var):
+        """Returns (out, generation): the handle now holds THIS pass's activations; an older pass can no longer be differentiated."""
+        if x.shape[0] > self.max_batch:
+            raise TrainerError("batch %d exceeds the handle's max_batch %d" % (x.shape[0], self.max_batch))
         out = torch.empty_like(x)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        self._ck(self._L.dbaz_trainer_forward(self.h, x.shape[0], x.data_ptr(), _ptr_array(conv_w), _ptr_array(conv_b),
-                                              _ptr_array(bn_w), _ptr_array(bn_b), _ptr_array(run_mean), _ptr_array(run_var),
-                                              out.data_ptr(), C.c_void_p(stream)))
-        return out
+        with torch.cuda.device(x.device):  # the C calls launch on the tensors' device, whatever torch's current device is
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            self._ck(self._L.dbaz_trainer_forward(self.h, x.shape[0], x.data_ptr(), _ptr_array(conv_w), _ptr_array(conv_b),
+                                                  _ptr_array(bn_w), _ptr_array(bn_b), _ptr_array(run_mean), _ptr_array(run_var),
+                                                  out.data_ptr(), C.c_void_p(stream)))
+        self.generation += 1
+        return out, self.generation
 
-    def backward(self, grad_out, bn_w, g_conv_w, g_conv_b, g_bn_w, g_bn_b):
+    def backward(self, grad_out, bn_w, g_conv_w, g_conv_b, g_bn_w, g_bn_b, generation=None):
+        if generation is not None and generation != self.generation:
+            raise TrainerError("backward of forward pass #%d, but the trainer handle now holds pass #%d: a handle keeps the activations "
+                               "of ONE forward pass (two micro-batches in one graph, or two graphs alive at once, need one "
+                               "TowerTrainer each -- train_tower.resblocks_forward(..., trainer=...))" % (generation, self.generation))
         gx = torch.empty_like(grad_out)
-        stream = torch.cuda.current_stream(grad_out.device).cuda_stream
-        self._ck(self._L.dbaz_trainer_backward(self.h, grad_out.data_ptr(), _ptr_array(bn_w), gx.data_ptr(), _ptr_array(g_conv_w),
-                                               _ptr_array(g_conv_b), _ptr_array(g_bn_w), _ptr_array(g_bn_b), C.c_void_p(stream)))
+        with torch.cuda.device(grad_out.device):
+            stream = torch.cuda.current_stream(grad_out.device).cuda_stream
+            self._ck(self._L.dbaz_trainer_backward(self.h, grad_out.data_ptr(), _ptr_array(bn_w), gx.data_ptr(), _ptr_array(g_conv_w),
+                                                   _ptr_array(g_conv_b), _ptr_array(g_bn_w), _ptr_array(g_bn_b), C.c_void_p(stream)))
         return gx
 
 
@@ -75,8 +86,8 @@ class _TowerFn(torch.autograd.Function):
         L = len(params) // 4
         cw, cb, bw, bb = ([params[4 * l + k].detach().contiguous() for l in range(L)] for k in range(4))
         xc = x.detach().contiguous().float()
-        out = trainer.forward(xc, cw, cb, bw, bb, run_mean, run_var)
-        ctx.trainer, ctx.bw, ctx.shapes = trainer, bw, [p.shape for p in params]
+        out, gen = trainer.forward(xc, cw, cb, bw, bb, run_mean, run_var)
+        ctx.trainer, ctx.bw, ctx.shapes, ctx.generation = trainer, bw, [p.shape for p in params], gen
         return out
 
     @staticmethod
@@ -85,32 +96,57 @@ class _TowerFn(torch.autograd.Function):
         dev = grad_out.device
         grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
         gx = ctx.trainer.backward(grad_out.contiguous().float(), ctx.bw, [grads[4 * l] for l in range(L)], [grads[4 * l + 1] for l in range(L)],
-                                  [grads[4 * l + 2] for l in range(L)], [grads[4 * l + 3] for l in range(L)])
+                                  [grads[4 * l + 2] for l in range(L)], [grads[4 * l + 3] for l in range(L)], generation=ctx.generation)
         return (None, None, None, gx) + tuple(grads)
 
 
-_trainers = {}
+_trainers = {}  # (id(model), H, W, blocks, device) -> TowerTrainer: one handle per MODEL, so two models of one shape never share activations
+
+
+def _bn_ok(bn):
+    # csrc/train.hip hard-codes torch's defaults: eps 1e-5, momentum 0.1, affine, running statistics, float32
+    return (bn.eps == 1e-5 and bn.momentum == 0.1 and bn.affine and bn.track_running_stats and bn.weight.dtype == torch.float32
+            and bn.running_mean is not None and bn.running_mean.dtype == torch.float32)
+
+
+def _conv_ok(conv, ch):
+    return (conv.in_channels == ch and conv.out_channels == ch and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is not None
+            and conv.weight.dtype == torch.float32)
 
 
 def supported(model, x):
-    """The HIP tower handles ResNetZero containers with 64 channels on a CUDA/HIP tensor."""
+    """The HIP tower handles ResNetZero containers with 64 channels on a float32 CUDA/HIP tensor whose blocks are exactly what
+    csrc/train.hip computes: 3x3 pad-1 convs with bias, BatchNorm2d with torch's default eps / momentum, affine, running statistics.
+    Anything else stays on torch (train.training_forward)."""
     r = getattr(model, "resnet", None)
-    return bool(x.is_cuda and r is not None and len(r.resblocks) > 0 and r.conv0.out_channels == 64)
+    if not (x.is_cuda and x.dtype == torch.float32 and r is not None and len(r.resblocks) > 0 and r.conv0.out_channels == 64):
+        return False
+    # the BatchNorm2d layers outside the blocks run on dbaz_bn2d_* (any eps / momentum, but a number); a bare block stack has none
+    outer = [getattr(model, "bn_input", None), getattr(r, "bn0", None), getattr(getattr(model, "policy_head", None), "bn0", None),
+             getattr(getattr(model, "value_head", None), "bn0", None)]
+    outer = [b for b in outer if b is not None]
+    if not all(b.affine and b.track_running_stats and b.momentum is not None and b.weight.dtype == torch.float32 for b in outer):
+        return False
+    return all(_conv_ok(c, 64) and _bn_ok(b) for blk in r.resblocks for c, b in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)))
 
 
-def resblocks_forward(model, x):
+def resblocks_forward(model, x, trainer=None):
     """x -> the output of model.resnet.resblocks in training mode (batch statistics; running stats and
-    num_batches_tracked updated), differentiable."""
+    num_batches_tracked updated), differentiable.  A trainer handle holds the activations of ONE forward pass: a second
+    forward through the same handle before the first one's backward makes that backward raise (TrainerError).  Pass your own
+    `trainer` (TowerTrainer) per live graph when several forward passes must be differentiated (micro-batches)."""
     r = model.resnet
     blocks = list(r.resblocks)
     H, W = x.shape[2], x.shape[3]
-    key = (H, W, len(blocks), x.device.index or 0)
-    tr = _trainers.get(key)
-    if tr is None or tr.max_batch < x.shape[0]:
-        if tr is not None:
-            tr.close()
-        tr = TowerTrainer(H - 1, W - 1, 64, len(blocks), max(int(x.shape[0]), 1), x.device.index or 0)
-        _trainers[key] = tr
+    tr = trainer
+    if tr is None:
+        key = (id(model), H, W, len(blocks), x.device.index or 0)
+        tr = _trainers.get(key)
+        if tr is None or tr.max_batch < x.shape[0]:
+            # (a smaller handle is NOT closed here: an autograd graph may still hold it; it is freed with its last reference)
+            tr = TowerTrainer(H - 1, W - 1, 64, len(blocks), max(int(x.shape[0]), 1), x.device.index or 0)
+            _trainers[key] = tr
     params, rm, rv, nbt = [], [], [], []
     for b in blocks:
         for conv, bn in ((b.conv1, b.bn1), (b.conv2, b.bn2)):
@@ -136,11 +172,12 @@ class _BNFn(torch.autograd.Function):
         mean = torch.empty(ch, dtype=torch.float32, device=xc.device)
         invstd = torch.empty_like(mean)
         ws = torch.empty(int(L.dbaz_bn2d_workspace_bytes(ch)) // 8, dtype=torch.float64, device=xc.device)
-        stream = C.c_void_p(torch.cuda.current_stream(xc.device).cuda_stream)
         w, b = weight.detach().contiguous(), bias.detach().contiguous()
-        rc = L.dbaz_bn2d_forward(xc.data_ptr(), n, ch, hw, w.data_ptr(), b.data_ptr(), run_mean.data_ptr(), run_var.data_ptr(),
-                                 float(eps), float(momentum), int(bool(relu)), out.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                 ws.data_ptr(), stream)
+        with torch.cuda.device(xc.device):  # dbaz_bn2d_* launch on the CURRENT device's stream: make it the tensor's
+            stream = C.c_void_p(torch.cuda.current_stream(xc.device).cuda_stream)
+            rc = L.dbaz_bn2d_forward(xc.data_ptr(), n, ch, hw, w.data_ptr(), b.data_ptr(), run_mean.data_ptr(), run_var.data_ptr(),
+                                     float(eps), float(momentum), int(bool(relu)), out.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                     ws.data_ptr(), stream)
         if rc != _lib.OK:
             raise TrainerError((L.dbaz_trainer_last_error(None) or b"dbaz_bn2d_forward failed").decode())
         ctx.save_for_backward(xc, out, w, mean, invstd)
@@ -155,9 +192,10 @@ class _BNFn(torch.autograd.Function):
         hw = xc.numel() // (n * ch)
         d = dout.contiguous().float()
         dx, dw, db = torch.empty_like(xc), torch.empty_like(w), torch.empty_like(w)
-        stream = C.c_void_p(torch.cuda.current_stream(xc.device).cuda_stream)
-        rc = L.dbaz_bn2d_backward(d.data_ptr(), out.data_ptr(), xc.data_ptr(), n, ch, hw, w.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                  int(ctx.relu), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ctx.ws.data_ptr(), stream)
+        with torch.cuda.device(xc.device):
+            stream = C.c_void_p(torch.cuda.current_stream(xc.device).cuda_stream)
+            rc = L.dbaz_bn2d_backward(d.data_ptr(), out.data_ptr(), xc.data_ptr(), n, ch, hw, w.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                      int(ctx.relu), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ctx.ws.data_ptr(), stream)
         if rc != _lib.OK:
             raise TrainerError((L.dbaz_trainer_last_error(None) or b"dbaz_bn2d_backward failed").decode())
         return dx, dw, db, None, None, None, None, None

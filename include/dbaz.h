@@ -40,6 +40,11 @@ extern "C" {
 #define DBAZ_ESTATE 5   /* call sequence error */
 
 #define DBAZ_MAX_A 256
+#define DBAZ_ABI_VERSION 3 /* dbaz_version(): bumped whenever dbaz_config / dbaz_counters change layout or meaning */
+
+/* dbaz_config.debug_flags */
+#define DBAZ_DBG_EARLY_JOIN 1u  /* join the driver pass in front of the network launch (round 2's first order) */
+#define DBAZ_DBG_NO_FALLBACK 2u /* skip the exact-f32 safety-net launch of nn_precision = 1 (timing runs only) */
 #define DBAZ_RESULT_NONE 2
 
 /* evaluator kinds (what plays the role of async_nn, mcts.py:187) */
@@ -68,19 +73,28 @@ typedef struct {
     uint64_t seed;          /* Philox key for move sampling / Dirichlet noise */
     int32_t max_out_rows;   /* capacity of the finished-sample buffer; 0 = max(4096, 2*n_slots*(E+1)) */
     int32_t nn_precision;   /* 0 = exact f32 MFMA; 1 = f16x3 split MFMA (f32-grade; an evaluation whose activations leave
-                             * f16's range is redone in exact f32 on the device, counters.f32_fallback_evals);
-                             * 2 = the arithmetic of 1 on the 32x32x16 MFMA tiling (64- and 128-channel ResNetZero; other
-                             * networks run as 1); 3 / 4 = 1 with the tiling of the layer kernel fixed (3: two cout tiles
-                             * per wave, 64 channels; 4: one) -- 1 picks between them, results are bit-identical */
+                             * f16's range is redone in exact f32 on the device, counters.f32_fallback_evals).  (A library built
+                             * with -DDBAZ_DEBUG also accepts the A/B tilings 2, 3, 4 of tools/ab_tilings.sh.) */
     int32_t match_play;     /* two-model match play (self_play.compute_elo, :309-344): the evaluator of a move's
                                search is model (root.to_play XOR game_idx&1) */
     int32_t evaluator2;     /* DBAZ_EVAL_* of model 1 (match play) */
     int32_t transposition_cache; /* 0 = on for network evaluators (default), 1 = off, 2 = on for network AND formula
                              * evaluators (parity tests of the hit path).  The reference caches (p, v) by position hash
                              * (utils/proxies.py:35-43); results are identical either way */
-    int32_t max_pending_evals; /* UCT_search's max_pending_evals (mcts.py:183): simulations of ONE tree in flight.  0 / 1 = the
-                             * sequential search (all parity paths, self-play); K > 1 = waves of up to K selections with
-                             * virtual loss, one batched evaluation per wave (dbaz_search / dbaz_search_timed only) */
+    int32_t max_pending_evals; /* UCT_search's max_pending_evals (mcts.py:183) = self_play.mcts.max_async_searches
+                             * (self_play.py:27-30): simulations of ONE tree in flight.  0 / 1 = the sequential search (all
+                             * parity paths); K > 1 = waves of up to K selections with virtual loss, one batched evaluation per
+                             * wave (dbaz_search / dbaz_search_timed, and the self-play driver when selfplay_pending != 0) */
+    int32_t selfplay_pending;  /* self-play driver (dbaz_run / dbaz_step): 0 = one simulation per game and step (default: the
+                             * batch comes from the concurrent games); 1 = every search of a game runs in waves of
+                             * max_pending_evals simulations with the reference's bookkeeping (visits added at backup,
+                             * mcts.py:105-132), as self_play.py:27-30 does with max_async_searches */
+    int32_t eval_round;     /* "full rounds only" (DESIGN 4): 0 = the network's own round size (workgroups per launch round x
+                             * samples per workgroup), -1 = off (every leaf is evaluated in the step that selected it),
+                             * r > 0 = rounds of r leaves (tests: small runs through the same path) */
+    int32_t eval_defer_max; /* with eval_round > 0: the largest left-over that is put off to the next step (0 = r - 1) */
+    uint32_t debug_flags;   /* measurement aids, 0 in production: DBAZ_DBG_* */
+    int32_t reserved[3];
 } dbaz_config;
 
 typedef struct {
@@ -109,7 +123,8 @@ typedef struct {
 } dbaz_counters;
 
 const char *dbaz_last_error(const dbaz_engine *e); /* e may be NULL: error of the last dbaz_create */
-int dbaz_version(void);
+int dbaz_version(void);            /* DBAZ_ABI_VERSION the library was built with */
+const char *dbaz_build_info(void); /* "src=<sha256[:16] of csrc/ + include/dbaz.h> nn=<the same of the network kernels>[ debug]": ties profiles/ counter files to a build */
 int dbaz_nodes_per_slot(const dbaz_engine *e); /* the node pool size in effect (dbaz_config.nodes_per_slot = 0: the default rule) */
 
 int dbaz_create(const dbaz_config *cfg, dbaz_engine **out);

@@ -139,6 +139,62 @@ def randomize_bn(model, seed):
     return model
 
 
+def trained_like_(model, X, seed, gamma_decades=3.0, var_decades=3.0, mean_sigmas=2.0):
+    """Give a ResNetZeroRef the STATISTICS of a trained network, layer by layer on the probe batch X (float32 [n,3,H,W]), in place:
+      * every conv's output channels are rescaled by log-uniform factors so that the variance a BatchNorm sees spreads over
+        `var_decades` decades inside ONE layer, and the layer's running_var is set to the variance actually observed on the probe
+        (what training does), running_mean to the observed mean shifted by up to +-mean_sigmas standard deviations;
+      * gamma is log-uniform over `gamma_decades` decades (geometric mean 0.5), beta ~ 0.3 gamma N(0,1);
+      * the residual stream is left to grow over the blocks as it does (it is NOT renormalised).
+    The folded per-channel weight scale gamma / sigma then spreads over >= gamma_decades decades per layer and the activations over
+    several decades between channels: what the f16x3 operand format (one power-of-two scale per layer) has to survive.
+    Returns the per-layer maxima of |activation| on the probe (conv0 output first)."""
+    g = torch.Generator().manual_seed(seed)
+    maxima = []
+
+    def logu(n, decades, centre=1.0):
+        return centre * torch.pow(10.0, (torch.rand(n, generator=g) - 0.5) * decades)
+
+    def fit(conv, bn, x, relu_after=True, skip=None):
+        n = conv.out_channels
+        s = logu(n, var_decades / 2.0)  # variance spreads over var_decades decades
+        conv.weight.mul_(s.view(-1, 1, 1, 1))
+        conv.bias.mul_(s)
+        y = conv(x)
+        mu, var = y.mean(dim=(0, 2, 3)), y.var(dim=(0, 2, 3), unbiased=False)
+        bn.running_var.copy_(var.clamp_min(1e-12))
+        bn.running_mean.copy_(mu + (torch.rand(n, generator=g) * 2 - 1) * mean_sigmas * var.sqrt())
+        bn.weight.copy_(logu(n, gamma_decades, 0.5))
+        bn.bias.copy_(0.3 * bn.weight * torch.randn(n, generator=g))
+        z = bn(y)
+        if skip is not None:
+            z = z + skip
+        return F.relu(z) if relu_after else z
+
+    model.train(False)
+    with torch.no_grad():
+        x = torch.as_tensor(X, dtype=torch.float32)
+        mu, var = x.mean(dim=(0, 2, 3)), x.var(dim=(0, 2, 3), unbiased=False)
+        model.bn_input.running_mean.copy_(mu)
+        model.bn_input.running_var.copy_(var.clamp_min(1e-6))
+        model.bn_input.weight.copy_(logu(x.shape[1], 1.0))
+        model.bn_input.bias.copy_(0.2 * torch.randn(x.shape[1], generator=g))
+        x = model.bn_input(x)
+        r = model.resnet
+        x = fit(r.conv0, r.bn0, x)
+        maxima.append(float(x.abs().max()))
+        for blk in r.resblocks:
+            y = fit(blk.conv1, blk.bn1, x)
+            maxima.append(float(y.abs().max()))
+            x = fit(blk.conv2, blk.bn2, y, skip=x)
+            maxima.append(float(x.abs().max()))
+        for head in (model.policy_head, model.value_head):
+            fit(head.conv0, head.bn0, x)
+            # heads: moderate gamma so that the logits stay O(1..10) (a trained policy is peaked, not saturated)
+            head.bn0.weight.copy_(logu(head.bn0.num_features, 1.0, 0.7))
+    return maxima
+
+
 def predict_sync(model, X):
     """NeuralNetWrapper.predict_sync (nn.py:155-160): eval mode, float32 in,
     (softmax p [n,A], tanh v [n,1]) numpy out."""

@@ -27,12 +27,12 @@ def test_library_exports_every_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in header_symbols():
         assert hasattr(L, name), name
-    assert _lib.load().dbaz_version() == 1
+    assert _lib.load().dbaz_version() == _lib.ABI_VERSION == 3
 
 
 def test_struct_sizes_match_header():
     # dbaz_config / dbaz_counters layouts as the C compiler sees them
-    assert ctypes.sizeof(_lib.Config) == 200
+    assert ctypes.sizeof(_lib.Config) == 232
     assert ctypes.sizeof(_lib.Counters) == 144
 
 

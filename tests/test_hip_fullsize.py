@@ -232,7 +232,7 @@ def test_config4_9x9_complete_games_vs_oracle_rules():
 
 
 @pytest.mark.parametrize("cut", [False, True])
-def test_config4_9x9_network_steps(monkeypatch, cut):
+def test_config4_9x9_network_steps(cut):
     """The fused trunk on 10x10 images (2 samples per workgroup, 13 position tiles) inside the self-play step at 2048
     slots: every expansion is a network evaluation, a cache hit or a terminal leaf."""
     import torch
@@ -242,9 +242,8 @@ def test_config4_9x9_network_steps(monkeypatch, cut):
     m = nn_ref.ResNetZeroRef(9, 9, 64, 4)
     nn_ref.randomize_bn(m, 2)
     K, n = 12, 2048
-    if not cut:
-        monkeypatch.setenv("DBAZ_EVAL_ROUND", "0")   # every leaf is evaluated in the step that selected it
-    e = Engine(9, 9, n, mcts_num_read=1600, noise=(0.8, 0.25), evaluator="resnet", nn_precision=1, seed=3)
+    # eval_round = -1: every leaf is evaluated in the step that selected it
+    e = Engine(9, 9, n, mcts_num_read=1600, noise=(0.8, 0.25), evaluator="resnet", nn_precision=1, seed=3, eval_round=0 if cut else -1)
     e.load_state_dict(m.state_dict(), "resnet", 64, 4, 16, 8)
     e.selfplay_fastforward((np.arange(n) * 37) % 120)
     e.selfplay_start(1 << 30, 0)

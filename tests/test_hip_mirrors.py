@@ -127,6 +127,34 @@ def test_generate_games_driver_contract():
     assert (first["move"] == -1).all() and (first["player"] == 0).all()
 
 
+def test_drop_in_entry_points_default_to_the_advertised_precision(monkeypatch):
+    """generate_games / compute_elo / NeuralNetWrapper with DEFAULT arguments run ResNetZero in nn_precision = 1 (f16x3), the mode
+    every number of README / bench.py is measured in (coach.py:27-29 is the reference call site); nn_precision=0 stays selectable."""
+    from dotsboxesaz_amd import engine as E
+    from dotsboxesaz_amd import nn as dnn
+    from dotsboxesaz_amd import self_play as sp
+    seen = []
+    real = E.Engine
+
+    class Spy(real):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            seen.append((self.cfg.evaluator, self.cfg.nn_precision))
+    monkeypatch.setattr(E, "Engine", Spy)
+    params = dnn.resnet_params(3, 3, 32, 1)
+    params["self_play"] = {"reuse_mcts_tree": True, "noise": [0.8, 0.25],
+                           "mcts": {"mcts_num_read": 10, "mcts_cpuct": [1.25, 19652], "temperature": {0: 1.0, 12: 0.02}}}
+    sp.generate_games(None, 0, dnn.ResNetZero, 4, params, rows=3, cols=3, n_slots=4)
+    sp.generate_games(None, 0, dnn.ResNetZero, 4, params, rows=3, cols=3, n_slots=4, nn_precision=0)
+    elo = {"n_games": 4, "self_play_override": {"reuse_mcts_tree": False, "noise": [0.0, 0.0], "mcts": {"mcts_num_read": 10}}}
+    sp.compute_elo(elo, [params, params], [0, 0], (1000.0, 1000.0), nn_classes=[dnn.ResNetZero, dnn.ResNetZero], rows=3, cols=3)
+    w = dnn.NeuralNetWrapper(dnn.ResNetZero(params), rows=3, cols=3, n_slots=8)
+    w.engine.close()
+    sp.generate_games(None, 0, dnn.SimpleNN, 2, params, rows=3, cols=3, n_slots=2)
+    R, S = E._lib.EVAL_RESNET, E._lib.EVAL_SIMPLENN
+    assert seen == [(R, 1), (R, 0), (R, 1), (R, 1), (S, 0)], seen
+
+
 def test_uct_search_time_limit_like_az_player():
     """players.AZPlayer: UCT_search(root, int(1e12), nn, time_limit=t) -- stops on the clock,
     returns the visits so far, and the tree stays usable (init_mcts_tree + another search)."""

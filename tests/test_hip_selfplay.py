@@ -415,11 +415,11 @@ def test_rows_do_not_depend_on_slot_scheduling():
         assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("rnd", ["16,15", "16,6", "7,6"])
-def test_full_rounds_only_changes_nothing_but_the_schedule(monkeypatch, rnd):
+@pytest.mark.parametrize("rnd", [(16, 15), (16, 6), (7, 6)])
+def test_full_rounds_only_changes_nothing_but_the_schedule(rnd):
     """Full rounds only (nn.hip cut_n): when a step's evaluation list would leave a few leaves behind the last full round of network workgroups,
     those leaves are put off to the next step (their slots keep the selected leaf).  Forced here with tiny rounds
-    (DBAZ_EVAL_ROUND=round,largest left-over that is put off): the 96 games' rows, visit counts and statistics are
+    (dbaz_config.eval_round = round, eval_defer_max = largest left-over that is put off): the 96 games' rows, visit counts and statistics are
     bit-identical to the run without the cut; only the number of steps differs."""
     import torch
     from dotsboxesaz_amd.engine import Engine
@@ -427,9 +427,9 @@ def test_full_rounds_only_changes_nothing_but_the_schedule(monkeypatch, rnd):
     torch.manual_seed(4)
     model = dnn.ResNetZero(dnn.resnet_params(3, 3, 32, 2, 4, 8))
     out, steps, exps = [], [], []
-    for env in ("0", rnd):
-        monkeypatch.setenv("DBAZ_EVAL_ROUND", env)
-        e = Engine(3, 3, 40, mcts_num_read=48, noise=(0.8, 0.25), reuse_tree=True, evaluator="resnet", seed=11)
+    for er, ed in ((-1, 0), rnd):
+        e = Engine(3, 3, 40, mcts_num_read=48, noise=(0.8, 0.25), reuse_tree=True, evaluator="resnet", seed=11, eval_round=er,
+                   eval_defer_max=ed)
         e.load_state_dict(model.state_dict(), "resnet", **model.shape)
         e.selfplay_start(96, 0)
         e.run()

@@ -159,6 +159,70 @@ def test_trainer_errors():
     t.close()
 
 
+def test_one_handle_holds_one_forward_pass():
+    """A trainer handle keeps the activations of ONE forward pass.  A second forward through the same handle before the first
+    graph's backward must make that backward RAISE (it used to return the gradients of the wrong batch); two models of one shape
+    get a handle each; a caller that needs two live graphs passes its own trainers."""
+    from dotsboxesaz_amd import train_tower
+
+    class M:
+        pass
+
+    def model(seed):
+        m = M()
+        m.resnet = M()
+        m.resnet.resblocks = make_blocks(1, seed).cuda()
+        m.resnet.resblocks.train(True)
+        return m
+    g = torch.Generator().manual_seed(1)
+    xa = torch.relu(torch.randn(6, 64, 7, 7, generator=g)).cuda().requires_grad_(True)
+    xb = torch.relu(torch.randn(9, 64, 7, 7, generator=g)).cuda().requires_grad_(True)  # a LARGER batch: the old handle must survive
+    m1, m2 = model(3), model(4)
+    train_tower._trainers.clear()
+    ya = train_tower.resblocks_forward(m1, xa)
+    yb = train_tower.resblocks_forward(m1, xb)      # same model: the handle (or its larger replacement) now holds pass b
+    with pytest.raises(train_tower.TrainerError):
+        ya.sum().backward()
+    yb.sum().backward()                             # the pass the handle holds still differentiates
+    assert xb.grad is not None and torch.isfinite(xb.grad).all()
+    # two models of the same shape: separate handles, both graphs alive
+    train_tower._trainers.clear()
+    y1 = train_tower.resblocks_forward(m1, xa)
+    y2 = train_tower.resblocks_forward(m2, xa)
+    assert len(train_tower._trainers) == 2
+    (y1.sum() + y2.sum()).backward()
+    # two micro-batches of ONE model summed into one loss: a trainer per live graph
+    t1 = train_tower.TowerTrainer(6, 6, 64, 1, 9)
+    t2 = train_tower.TowerTrainer(6, 6, 64, 1, 9)
+    xa2, xb2 = xa.detach().clone().requires_grad_(True), xb.detach().clone().requires_grad_(True)
+    ref = copy.deepcopy(m1.resnet.resblocks)
+    loss = train_tower.resblocks_forward(m1, xa2, trainer=t1).sum() + train_tower.resblocks_forward(m1, xb2, trainer=t2).sum()
+    loss.backward()
+    xr = xa.detach().clone().requires_grad_(True)
+    ref(xr).sum().backward()
+    assert float((xa2.grad - xr.grad).abs().max()) < 1e-3 * float(xr.grad.abs().max())
+    t1.close()
+    t2.close()
+    train_tower._trainers.clear()
+
+
+def test_unsupported_batchnorm_settings_stay_on_torch():
+    """csrc/train.hip hard-codes eps 1e-5 / momentum 0.1 / affine / running statistics: any other BatchNorm setting must not be
+    routed to it (train_tower.supported)."""
+    from dotsboxesaz_amd import nn as dnn
+    from dotsboxesaz_amd import train_tower
+    m = dnn.ResNetZero(dnn.resnet_params(3, 3, 64, 1)).cuda()
+    x = torch.zeros(2, 3, 4, 4, device="cuda")
+    assert train_tower.supported(m, x)
+    m.resnet.resblocks[0].bn1.eps = 1e-3
+    assert not train_tower.supported(m, x)
+    m.resnet.resblocks[0].bn1.eps = 1e-5
+    m.resnet.resblocks[0].bn2.momentum = None
+    assert not train_tower.supported(m, x)
+    m.resnet.resblocks[0].bn2.momentum = 0.1
+    assert train_tower.supported(m, x) and not train_tower.supported(m, x.double()) and not train_tower.supported(m.double(), x)
+
+
 def test_train_steps_hip_tower_vs_torch_tower():
     """NeuralNetWrapper.train's step (nn.py:203-221: forward, AlphaZeroLoss, backward, SGD momentum + weight decay) on a
     64-channel ResNetZero for a few batches: residual blocks on csrc/train.hip against the same container with the blocks
@@ -277,8 +341,11 @@ def test_batch_norm_train_vs_torch_float64(ch, hw, n, relu):
 
 
 def test_exact_f32_weight_gradient_path(monkeypatch):
-    """DBAZ_TRAIN_WGRAD_F32=1 selects k_wgrad (v_mfma_f32_16x16x4_f32, exact products) instead of k_wgrad_h3: same gradients."""
-    from dotsboxesaz_amd import train_tower
+    """Debug build only (-DDBAZ_DEBUG, DBAZ_LIB=.../libdbaz_hip_debug.so): DBAZ_TRAIN_WGRAD_F32=1 selects k_wgrad
+    (v_mfma_f32_16x16x4_f32, exact products) instead of k_wgrad_h3: same gradients.  The release library reads no environment."""
+    from dotsboxesaz_amd import train_tower, _lib
+    if "debug" not in _lib.load().dbaz_build_info().decode():
+        pytest.skip("release build: the exact-f32 weight gradient kernel is an A/B path of the debug build")
     blocks = make_blocks(1, 5)
     g = torch.Generator().manual_seed(9)
     x = torch.relu(torch.randn(21, 64, 7, 7, generator=g))

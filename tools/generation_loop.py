@@ -3,7 +3,7 @@
 (HIP) -> dataset + batches (HIP) -> optimizer steps (residual tower and batch norms on HIP, the rest torch) -> weights back
 into the engine.  6x6, ResNetZero 20x64, 800 sims/move.  Prints one JSON line.
 
-    python tools/generation_loop.py [games per generation] [last generation]"""
+    python tools/generation_loop.py [games per generation] [last generation] [file to copy the last checkpoint to]"""
 import json
 import os
 import sys
@@ -47,6 +47,11 @@ for g in range(last + 1):
     steps = last_idx - last_idx0
     out["generations"].append({"generation": g, "selfplay_s": t1 - t0, "games": games, "rows": sp.get("rows"), "games_per_sec": games / (t1 - t0),
                                "train_s": t2 - t1, "train_steps": steps, "ms_per_train_step_incl_data_and_validation": 1e3 * (t2 - t1) / max(1, steps),
-                               "last_batch_idx": last_idx})
+                               "last_batch_idx": last_idx, "nn_evals": sp.get("nn_evals"), "f32_fallback_evals": sp.get("f32_fallback_evals"),
+                               "f32_fallback_fraction": (sp.get("f32_fallback_evals") or 0) / max(1, sp.get("nn_evals") or 0),
+                               "pool_resets": sp.get("pool_resets"), "moves_played": sp.get("moves_played")})
+if len(sys.argv) > 3:  # keep the last generation's checkpoint (tests/test_hip_nn.py's trained-weights case reads it)
+    import shutil
+    shutil.copy(params["nn"]["chkpts_filename"].format(last), sys.argv[3])
 coach.close()
 print(json.dumps(out))  # (train() prints its epoch lines before this one: take the last line)

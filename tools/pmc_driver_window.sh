@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC counters of the main k_tower launch over the TIMED WINDOW of the driver's own bench command (its last K launches):
-#   bash tools/pmc_driver_window.sh [steps] [warmup]     -> gpurun_out/pmc_driver_window/summary.json (committed as profiles/r02_pmc_tower_driver_window.json)
+#   bash tools/pmc_driver_window.sh [steps] [warmup]     -> gpurun_out/pmc_driver_window/summary.json (committed as profiles/r03_pmc_tower_driver_window.json)
 # One counter group per rocprofv3 run, --kernel-trace only beside --pmc (MI355X_MICROARCH.md, HBM / rocprofv3 section).
 K=${1:-20}; W=${2:-5}
 repo=$PWD
@@ -14,6 +14,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFM
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pass$i -o p -- python3 bench.py --gpus 1 --steps $K --warmup $W --games-leg 0 --no-cpu-baseline --no-f32-side-run > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed"
   echo "pass $i ($grp) done"
 done
-python3 tools/pmc_summary.py $OUT $OUT/summary.json --last $K   # copy to profiles/r02_pmc_tower_driver_window.json
+python3 tools/pmc_summary.py $OUT $OUT/summary.json --last $K   # copy to profiles/r03_pmc_tower_driver_window.json
 tail -n 1 $OUT/pass1.json > $OUT/bench_line_under_pmc.json
 find $OUT -name "*.csv" -size +1M -delete

@@ -67,8 +67,20 @@ def main(src, dst, last=0):
         busy, gui = t.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("mean"), t.get("GRBM_GUI_ACTIVE", {}).get("mean")
         if busy and gui:
             t["mfma_busy_frac"] = busy / (gui / 8.0 * 1024.0)
+    # the build the counters were taken on and the evaluations per launch: from the bench line of the first pass
+    import os
+    line = os.path.join(src, "pass1.json")
+    if os.path.exists(line):
+        try:
+            b = json.loads(open(line).read().strip().splitlines()[-1])
+            out["build"] = b.get("build")
+            out["steps"], out["warmup"] = b.get("steps"), b.get("warmup")
+            if b.get("roofline", {}).get("flops_per_launch"):
+                out["evals_per_launch"] = b["nn_evals_per_sec"] * b["ms_per_step"] * 1e-3
+        except (ValueError, KeyError):
+            pass
     json.dump(out, open(dst, "w"), indent=1)
-    print(json.dumps({k: out.get(k) for k in ("traffic_bytes_per_launch", "mfma_busy_frac")}))
+    print(json.dumps({k: out.get(k) for k in ("traffic_bytes_per_launch", "mfma_busy_frac", "evals_per_launch", "build")}))
 
 
 if __name__ == "__main__":
