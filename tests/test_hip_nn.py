@@ -297,7 +297,7 @@ def test_f16x3_on_trained_like_statistics_20x64(seed):
     m = nn_ref.ResNetZeroRef(6, 6, 64, 20)
     maxima = nn_ref.trained_like_(m, _positions(6, 6, 256, seed), seed)
     for name, bn in (("first", m.resnet.resblocks[0].bn1), ("last", m.resnet.resblocks[19].bn2)):
-        sc = (bn.weight / (bn.running_var + 1e-5).sqrt()).abs()
+        sc = (bn.weight / (bn.running_var + 1e-5).sqrt()).abs().detach()
         assert float(sc.max() / sc.min()) > 1e3 and float(bn.running_var.max() / bn.running_var.min()) > 5e2, name
     assert max(maxima) > 50.0                                   # the stream did grow
     n = 1500

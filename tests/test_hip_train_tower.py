@@ -176,15 +176,22 @@ def test_one_handle_holds_one_forward_pass():
         return m
     g = torch.Generator().manual_seed(1)
     xa = torch.relu(torch.randn(6, 64, 7, 7, generator=g)).cuda().requires_grad_(True)
-    xb = torch.relu(torch.randn(9, 64, 7, 7, generator=g)).cuda().requires_grad_(True)  # a LARGER batch: the old handle must survive
+    xb = torch.relu(torch.randn(9, 64, 7, 7, generator=g)).cuda().requires_grad_(True)
+    xc = torch.relu(torch.randn(4, 64, 7, 7, generator=g)).cuda().requires_grad_(True)
     m1, m2 = model(3), model(4)
     train_tower._trainers.clear()
     ya = train_tower.resblocks_forward(m1, xa)
-    yb = train_tower.resblocks_forward(m1, xb)      # same model: the handle (or its larger replacement) now holds pass b
+    yc = train_tower.resblocks_forward(m1, xc)      # same model, fits the same handle: the handle now holds pass c
     with pytest.raises(train_tower.TrainerError):
         ya.sum().backward()
-    yb.sum().backward()                             # the pass the handle holds still differentiates
-    assert xb.grad is not None and torch.isfinite(xb.grad).all()
+    yc.sum().backward()                             # the pass the handle holds still differentiates
+    assert xc.grad is not None and torch.isfinite(xc.grad).all()
+    # a LARGER batch makes a new handle; the old one is not closed under the graph that still references it
+    ya = train_tower.resblocks_forward(m1, xa)
+    yb = train_tower.resblocks_forward(m1, xb)
+    ya.sum().backward()
+    yb.sum().backward()
+    assert torch.isfinite(xa.grad).all() and torch.isfinite(xb.grad).all()
     # two models of the same shape: separate handles, both graphs alive
     train_tower._trainers.clear()
     y1 = train_tower.resblocks_forward(m1, xa)
