@@ -409,7 +409,7 @@ def tower_roofline(args, m, steps, precision):
     peak = F32_MFMA_PEAK_TFLOPS if precision == 0 else F16_MFMA_PEAK_TFLOPS / 3.0
     return {"bound": "mfma",
             "kernel": "k_tower<%d,*,%s> (conv0 + 2*%d conv3x3 + head 1x1 convs fused, LDS-resident)"
-                      % (args.channels, {0: "f32", 1: "f16x3 on 16x16x32 (two cout tiles per wave at 64 channels)", 2: "f16x3 on 32x32x16", 3: "f16x3 on 16x16x32, two cout tiles per wave", 4: "f16x3 on 16x16x32, one cout tile per wave"}[precision], args.blocks),
+                      % (args.channels, {0: "f32", 1: "f16x3 on 16x16x32 (two cout tiles per wave at 64 channels)", 2: "f16x3 on 32x32x16", 3: "f16x3 on 16x16x32, two cout tiles per wave", 4: "f16x3 on 16x16x32, one cout tile per wave"}.get(precision, "f16x3, A/B variant %d of the debug build" % precision), args.blocks),
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "peak_note": ("dense f32 MFMA" if precision == 0 else
                           "dense f16 MFMA / 3 (three f16 MFMAs per f32-grade product); algorithmic flops counted once"),
@@ -430,7 +430,7 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "simplenn", "formula", "uniform"])
-    ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--precision", type=int, default=1, choices=list(range(14)),
                     help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default); 2 / 3 / 4 = A/B tilings of the "
                          "f16x3 layer, debug build only (DBAZ_LIB=dotsboxesaz_amd/libdbaz_hip_debug.so; EXPERIMENTS.md)")
     ap.add_argument("--debug-flags", type=int, default=0, help="dbaz_config.debug_flags (1 = early join, 2 = no f32 fallback launch)")

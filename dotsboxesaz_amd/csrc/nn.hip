@@ -88,6 +88,7 @@ struct NNState {
     int want_c2 = 0, c2 = 0, S_c2 = 0, NT_c2 = 0; // (its remainder goes to the one-cout-tile kernels)
     int use_rem = 0; // f16x3, NTT == 7: the remainder sizes live in ONE launch (k_tower_rem)
     bool no_fallback = false; // dbaz_config.debug_flags & DBAZ_DBG_NO_FALLBACK (timing runs only)
+    int variant = 5;          // VAR of the main two-cout-tile launch (conv_lds_h3_c2): 5 = shipped; the debug build selects others
     size_t conv_lds_c2 = 0;
 };
 
@@ -222,13 +223,19 @@ __device__ __forceinline__ void wpre_load(WPre &pre, const f32x4 *wpk_layer, int
     pre.l1 = wb[192];
 }
 
-template <int C, int NTT>
+template <int C, int NTT, bool RR = false>
 __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
                                             const float *__restrict__ bias, float oscale, const int *vm, int rowbase,
                                             int zbase, int W, int R, int wave, int lane, int residual, bool &ovf_out, int tbase,
                                             const float *post_s, const float *post_t, WPre &pre, const f32x4 *next_wpk,
-                                            unsigned long long *stamps = nullptr)
+                                            f32x4 (&res)[NTT], unsigned long long *stamps = nullptr)
 {
+    // RR (the remainder bodies that run beside conv_lds_h3_c2's main launch, 64 channels): a wave owns ONE cout tile, the same
+    // outputs in every layer, so the block's residual input stays in its f32 registers (res, activation-scaled) exactly as in
+    // conv_lds_h3_c2 -- the two kernels must round identically: a sample's (p, v) may not depend on which of them evaluated it.
+    // Otherwise (!RR: geometries whose main launch is this kernel, e.g. 9x9 with its 7-tile waves, which have no 28 registers
+    // to spare) the residual is decoded from the (hi, lo) image in LDS, in every body of that geometry alike.
+    static_assert(!RR || C <= 64, "one cout tile per wave");
 
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     (void)t0; (void)t1; (void)t2; (void)t3; (void)stamps;
@@ -321,13 +328,15 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
         _Float16 *dsth = reinterpret_cast<_Float16 *>(dst4);
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         u32x2 rh[NTT], rl[NTT];
-        if (residual) {
+        if constexpr (!RR) {
+            if (residual) {
 #pragma unroll
-            for (int t = 0; t < NTT; t++) {
-                const int row = min((tbase + t) * 16 + jrow, R - 1);
-                const _Float16 *ph = dsth + (size_t)row * (S4 * 8) + ct * 16 + gq * 4;
-                rh[t] = *reinterpret_cast<const u32x2 *>(ph);
-                rl[t] = *reinterpret_cast<const u32x2 *>(ph + C);
+                for (int t = 0; t < NTT; t++) {
+                    const int row = min((tbase + t) * 16 + jrow, R - 1);
+                    const _Float16 *ph = dsth + (size_t)row * (S4 * 8) + ct * 16 + gq * 4;
+                    rh[t] = *reinterpret_cast<const u32x2 *>(ph);
+                    rl[t] = *reinterpret_cast<const u32x2 *>(ph + C);
+                }
             }
         }
         float vmax = 0.0f;
@@ -336,15 +345,22 @@ __device__ __forceinline__ void conv_lds_h3(const f32x4 *__restrict__ src4, f32x
             const int row = (tbase + t) * 16 + jrow;
             f32x4 v = acc[t] * oscale + bv; // activation-scaled: value * 2^ACT_SHIFT
             if (residual) {
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                union { unsigned int u; h2 h; } c0, c1, d0, d1;
-                c0.u = rh[t][0]; c1.u = rh[t][1]; d0.u = rl[t][0]; d1.u = rl[t][1];
-                v[0] += (float)c0.h[0] + (float)d0.h[0];
-                v[1] += (float)c0.h[1] + (float)d0.h[1];
-                v[2] += (float)c1.h[0] + (float)d1.h[0];
-                v[3] += (float)c1.h[1] + (float)d1.h[1];
+                if constexpr (RR) {
+                    v += res[t];
+                } else {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    union { unsigned int u; h2 h; } c0, c1, d0, d1;
+                    c0.u = rh[t][0]; c1.u = rh[t][1]; d0.u = rl[t][0]; d1.u = rl[t][1];
+                    v[0] += (float)c0.h[0] + (float)d0.h[0];
+                    v[1] += (float)c0.h[1] + (float)d0.h[1];
+                    v[2] += (float)c1.h[0] + (float)d1.h[0];
+                    v[3] += (float)c1.h[1] + (float)d1.h[1];
+                }
             }
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            if constexpr (RR) {
+                if (residual) res[t] = v; // the block's output = the next block's residual input
+            }
             if (post_s) { // SimpleNN: BatchNorm follows the ReLU; post_t is pre-scaled
                 v = v * *reinterpret_cast<const f32x4 *>(post_s + ct * 16 + gq * 4) +
                     *reinterpret_cast<const f32x4 *>(post_t + ct * 16 + gq * 4);
@@ -399,11 +415,39 @@ __device__ __forceinline__ void wpre_load_c2(WPre (&pre)[2], const f32x4 *wpk_la
     }
 }
 
-template <int C, int NTT>
+// VAR (A/B variants, EXPERIMENTS.md "k_tower, round 3"; the shipped kernel is VAR = 0):
+//   1  the block's residual input stays in f32 registers of the wave that owns those outputs in every layer (no LDS decode)
+//   2  the 16-byte column chunks of an LDS row are XOR-swizzled by (row >> 2) & 3: the epilogue's ds_write_b64 then conflict
+//      2-way instead of 4-way, the fragment reads stay conflict-free
+//   8  waves 4-7 (the younger wave of every SIMD, which loses every arbitration) run at s_setprio 1
+//   4  the layer's weight fragments reach the workgroup ONCE per K-step, by LDS-DMA into a two-slot ring behind the activation
+//      images (each wave fetches one of the step's eight 1-KB fragments), instead of four times into registers: a quarter of
+//      the L2 -> CU weight stream, four more LDS fragment reads and one workgroup barrier per K-step
+#define VAR_RESREG 1
+#define VAR_SWZ 2
+#define VAR_WLDS 4
+#define VAR_PRIO 8
+#define VAR_LO0 16 // timing bound only (wrong results): every lo half zero -- what operand toggling in the two cross-term MFMAs costs
+#define VAR_LO8 32 // the lo halves carry 8 significant bits instead of 11 (3 trailing zero mantissa bits; 19-bit products)
+#define WRING_UNITS 512 // 16-byte units per ring slot: 4 cout tiles x (hi, lo) x 64 lanes
+
+// LDS-DMA of 16 bytes per lane: lane's global source -> lds_dst (wave-uniform LDS byte address) + 16 * lane
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
+}
+template <int C, int NTT, int VAR = 0>
 __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
                                                const float *__restrict__ bias, float oscale, const int *vm, int rowbase,
                                                int zbase, int W, int R, int wave, int lane, int residual, bool &ovf_out, int tbase,
-                                               WPre (&pre)[2], const f32x4 *next_wpk, unsigned long long *stamps = nullptr)
+                                               WPre (&pre)[2], const f32x4 *next_wpk, f32x4 (&res)[2][NTT],
+                                               unsigned long long *stamps = nullptr, f32x4 *wring = nullptr)
 {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     (void)t0; (void)t1; (void)t2; (void)t3; (void)stamps;
@@ -425,12 +469,40 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
     u128h bh[NTT], bl[NTT];
     const char *sb = reinterpret_cast<const char *>(src4);
     int ab[NTT];
+    // 16-byte unit of this lane's fragment of tile 0 for a tap at row offset offr (the tile constant t*16*S4 is an immediate;
+    // with VAR_SWZ the chunk index gq is XORed with (source row >> 2) & 3, which does not depend on the tile: 16 | tile rows)
+    const int row0 = tbase * 16 + jrow;
+    auto tap_unit = [&](int offr) -> int {
+        if constexpr (VAR & VAR_SWZ) {
+            const int su = row0 + offr;
+            return su * S4 + (gq ^ ((su >> 2) & 3));
+        } else {
+            return rowbase + offr * S4;
+        }
+    };
+    {
+        const int u0 = tap_unit(-W - 1);
 #pragma unroll
-    for (int t = 0; t < NTT; t++)
-        ab[t] = ((vm[t] & 1) ? rowbase + (-W - 1) * S4 : zbase + ((rowbase + (-W - 1) * S4) & 15) - t * 16 * S4) * 16;
+        for (int t = 0; t < NTT; t++) ab[t] = ((vm[t] & 1) ? u0 : zbase + (u0 & 15) - t * 16 * S4) * 16;
+    }
     STAMP(t0);
+    // VAR_WLDS: this wave's DMA piece of a step = fragment (cout tile wave >> 1, hi | lo = wave & 1); the fragments it consumes are
+    // those of cout tiles ct0, ct0 + 1: ring units (ct * 2 + hl) * 64 + lane of slot (step & 1)
+    const f32x4 *dsrc = wpk + ((size_t)(wave >> 1) * N * 2 + (wave & 1)) * 64 + lane;
+    const f32x4 *dnext = next_wpk ? next_wpk + ((size_t)(wave >> 1) * N * 2 + (wave & 1)) * 64 + lane : nullptr;
+    const f32x4 *rsrc = wring + (size_t)ct0 * 2 * 64 + lane;
+    unsigned ring_dst = 0;
+    if constexpr (VAR & VAR_WLDS) {
+        static_assert(!(VAR & VAR_WLDS) || N % 2 == 0, "the next layer's step 0 must land in slot 0");
+        ring_dst = __builtin_amdgcn_readfirstlane(lds_addr(wring + (size_t)wave * 64));
+        // step 0's fragments were taken out of slot 0 BEFORE the layer barrier (below / tower_group's prologue): step 0 refills
+        // that slot at once, and a wave late out of the barrier must not find another wave's DMA there
 #pragma unroll
-    for (int c = 0; c < 2; c++) { a_h[c][0].f = pre[c].h0; a_l[c][0].f = pre[c].l0; a_h[c][1].f = pre[c].h1; a_l[c][1].f = pre[c].l1; }
+        for (int c = 0; c < 2; c++) { a_h[c][0].f = pre[c].h0; a_l[c][0].f = pre[c].l0; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 2; c++) { a_h[c][0].f = pre[c].h0; a_l[c][0].f = pre[c].l0; a_h[c][1].f = pre[c].h1; a_l[c][1].f = pre[c].l1; }
+    }
 #pragma unroll
     for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4);
 #pragma unroll
@@ -438,9 +510,19 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
     STAMP(t1);
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        const int cur = i % 3, nxt = (i + 2) % 3;
+        // register set of step i's weight fragments: a 3-deep ring fed from L2, or (VAR_WLDS) two sets fed from the LDS ring
+        const int cur = (VAR & VAR_WLDS) ? (i & 1) : i % 3, nxt = (VAR & VAR_WLDS) ? ((i + 1) & 1) : (i + 2) % 3;
         const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
-        if (i + 2 < N) {
+        if constexpr (VAR & VAR_WLDS) {
+            // step i + 2's piece -> slot i & 1 (every wave read step i's fragments out of it before the last barrier); behind the
+            // layer's last steps: the first two steps of the next layer
+            if (i + 2 < N) glds16(dsrc + (size_t)(i + 2) * 128, ring_dst + (i & 1) * (WRING_UNITS * 16));
+            else if (dnext) glds16(dnext + (size_t)(i + 2 - N) * 128, ring_dst + (i & 1) * (WRING_UNITS * 16));
+            if (ni < N) { // step i + 1's fragments out of slot (i + 1) & 1 (landed and fenced by the barrier that ended step i - 1)
+                const f32x4 *r1 = rsrc + (size_t)(ni & 1) * WRING_UNITS;
+                a_h[0][nxt].f = r1[0]; a_l[0][nxt].f = r1[64]; a_h[1][nxt].f = r1[128]; a_l[1][nxt].f = r1[192];
+            }
+        } else if (i + 2 < N) {
             a_h[0][nxt].f = wb0[(size_t)(i + 2) * 128];
             a_l[0][nxt].f = wb0[(size_t)(i + 2) * 128 + 64];
             a_h[1][nxt].f = wb1[(size_t)(i + 2) * 128];
@@ -454,10 +536,10 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
             acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[1][cur].h, bh[t].h, acc[1][t], 0, 0, 0);
         }
         if (ni < N && nks == 0) {
-            const int off = ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
-            const int zt = zbase + ((rowbase + off) & 15);
+            const int un = tap_unit((ntap / 3 - 1) * W + (ntap % 3 - 1));
+            const int zt = zbase + (un & 15);
 #pragma unroll
-            for (int t = 0; t < NTT; t++) ab[t] = (((vm[t] >> ntap) & 1) ? rowbase + off : zt - t * 16 * S4) * 16;
+            for (int t = 0; t < NTT; t++) ab[t] = (((vm[t] >> ntap) & 1) ? un : zt - t * 16 * S4) * 16;
         }
         __builtin_amdgcn_sched_barrier(0);
         // lo*hi; bh[t] is dead after its second MFMA -> reload it for the next step right there
@@ -476,6 +558,14 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
             if (ni < N) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64 + LO * 16);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (VAR & VAR_WLDS) {
+            // end of step i: this wave's DMA piece has landed (vmcnt) and its ring reads of step i + 1 have returned (LDS returns in
+            // order; only the 2 * NTT activation reads issued after them may still be out) -- then every wave's have
+            if (ni < N) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(%0)" ::"n"(2 * NTT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ni < N) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     STAMP(t2);
     f32x4 bv[2];
@@ -485,7 +575,12 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
         asm volatile("" ::"v"(bv[c]));
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (next_wpk) wpre_load_c2<C>(pre, next_wpk, wave, lane);
+    if constexpr (!(VAR & VAR_WLDS)) {
+        if (next_wpk) wpre_load_c2<C>(pre, next_wpk, wave, lane);
+    } else if (next_wpk) {
+        // the next layer's step 0 (slot 0: DMAed in step N - 2, fenced by that step's barrier) into registers before the layer barrier
+        pre[0].h0 = rsrc[0]; pre[0].l0 = rsrc[64]; pre[1].h0 = rsrc[128]; pre[1].l0 = rsrc[192];
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue (as conv_lds_h3): lane holds couts (ct0 + c) * 16 + 4 gq .. +3 of position row (tbase + t) * 16 + jrow
     _Float16 *dsth = reinterpret_cast<_Float16 *>(dst4);
@@ -495,14 +590,19 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
     float vmax = 0.0f;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
+        // column (in halves) of this lane's 4 couts inside a row
+        int col = (ct0 + c) * 16 + gq * 4;
+        if constexpr (VAR & VAR_SWZ) col = ((((ct0 + c) * 2 + (gq >> 1)) ^ ((jrow >> 2) & 3)) * 8) + (gq & 1) * 4;
         u32x2 rh[NTT], rl[NTT];
-        if (residual) {
+        if constexpr (!(VAR & VAR_RESREG)) {
+            if (residual) {
 #pragma unroll
-            for (int t = 0; t < NTT; t++) {
-                const int row = min((tbase + t) * 16 + jrow, R - 1);
-                const _Float16 *ph = dsth + (size_t)row * (S4 * 8) + (ct0 + c) * 16 + gq * 4;
-                rh[t] = *reinterpret_cast<const u32x2 *>(ph);
-                rl[t] = *reinterpret_cast<const u32x2 *>(ph + C);
+                for (int t = 0; t < NTT; t++) {
+                    const int row = min((tbase + t) * 16 + jrow, R - 1);
+                    const _Float16 *ph = dsth + (size_t)row * (S4 * 8) + col;
+                    rh[t] = *reinterpret_cast<const u32x2 *>(ph);
+                    rl[t] = *reinterpret_cast<const u32x2 *>(ph + C);
+                }
             }
         }
 #pragma unroll
@@ -510,14 +610,21 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
             const int row = (tbase + t) * 16 + jrow;
             f32x4 v = acc[c][t] * oscale + bv[c];
             if (residual) {
-                union { unsigned int u; h2v h; } c0, c1, d0, d1;
-                c0.u = rh[t][0]; c1.u = rh[t][1]; d0.u = rl[t][0]; d1.u = rl[t][1];
-                v[0] += (float)c0.h[0] + (float)d0.h[0];
-                v[1] += (float)c0.h[1] + (float)d0.h[1];
-                v[2] += (float)c1.h[0] + (float)d1.h[0];
-                v[3] += (float)c1.h[1] + (float)d1.h[1];
+                if constexpr (VAR & VAR_RESREG) {
+                    v += res[c][t];
+                } else {
+                    union { unsigned int u; h2v h; } c0, c1, d0, d1;
+                    c0.u = rh[t][0]; c1.u = rh[t][1]; d0.u = rl[t][0]; d1.u = rl[t][1];
+                    v[0] += (float)c0.h[0] + (float)d0.h[0];
+                    v[1] += (float)c0.h[1] + (float)d0.h[1];
+                    v[2] += (float)c1.h[0] + (float)d1.h[0];
+                    v[3] += (float)c1.h[1] + (float)d1.h[1];
+                }
             }
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            if constexpr (VAR & VAR_RESREG) {
+                if (residual) res[c][t] = v; // the block's output = the next block's residual input
+            }
             vmax = fmaxf(vmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
             union { h2v h[2]; u32x2 u; } oh, ol;
 #pragma unroll
@@ -527,8 +634,10 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
                 oh.h[q] = h;
                 ol.h[q] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
             }
+            if constexpr (VAR & VAR_LO0) ol.u = (u32x2){0u, 0u};
+            if constexpr (VAR & VAR_LO8) ol.u &= (u32x2){0xFFF8FFF8u, 0xFFF8FFF8u};
             if (row < R) {
-                _Float16 *ph = dsth + (size_t)row * (S4 * 8) + (ct0 + c) * 16 + gq * 4;
+                _Float16 *ph = dsth + (size_t)row * (S4 * 8) + col;
                 *reinterpret_cast<u32x2 *>(ph) = oh.u;
                 *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
             }
@@ -724,7 +833,14 @@ __device__ __forceinline__ void conv_lds_h3_32(const f32x4 *__restrict__ src4, f
 // from L2.  PREC 0: exact f32 (rows hold C floats); PREC 1: f16x3 (rows hold C hi + C lo halves
 // of the activation scaled by 2^ACT_SHIFT).
 // ------------------------------------------------------------------------------------
-template <int C, int PREC, int STRIDE = C + 8>
+// index (in halves) of channel c inside the hi part of LDS row `row` (VAR_SWZ: 16-byte chunks XORed with (row >> 2) & 3)
+template <int SWZ>
+__device__ __forceinline__ int act_col(int row, int c)
+{
+    if constexpr (SWZ) return (((c >> 3) ^ ((row >> 2) & 3)) << 3) | (c & 7);
+    else return c;
+}
+template <int C, int PREC, int STRIDE = C + 8, int SWZ = 0>
 __device__ __forceinline__ void act_store(float *lds, int row, int c, float v, bool &ovf)
 {
     if constexpr (PREC == 0) {
@@ -734,18 +850,20 @@ __device__ __forceinline__ void act_store(float *lds, int row, int c, float v, b
         const float x = v * ACT_SCALE;
         ovf |= fabsf(x) > F16_GUARD;
         const _Float16 hi = (_Float16)x;
-        h[c] = hi;
-        h[C + c] = (_Float16)(x - (float)hi);
+        const int cc = act_col<SWZ>(row, c);
+        h[cc] = hi;
+        h[C + cc] = (_Float16)(x - (float)hi);
     }
 }
-template <int C, int PREC, int STRIDE = C + 8>
+template <int C, int PREC, int STRIDE = C + 8, int SWZ = 0>
 __device__ __forceinline__ float act_load(const float *lds, int row, int c)
 {
     if constexpr (PREC == 0) {
         return lds[row * STRIDE + c];
     } else {
         const _Float16 *h = reinterpret_cast<const _Float16 *>(lds) + (size_t)row * (STRIDE * 2);
-        return ((float)h[c] + (float)h[C + c]) * (1.0f / ACT_SCALE);
+        const int cc = act_col<SWZ>(row, c);
+        return ((float)h[cc] + (float)h[C + cc]) * (1.0f / ACT_SCALE);
     }
 }
 
@@ -784,10 +902,12 @@ struct TowerArgs {
 };
 
 // the S samples [s0, s0 + ns) of one workgroup through the whole trunk
-template <int C, int NTA, int NTB, int PREC, int MF>
+template <int C, int NTA, int NTB, int PREC, int MF, int VAR = 0>
 __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, float *lds, const int S, const int s0, const int ns)
 {
     static_assert(MF == 0 || PREC == 1, "the alternative tilings exist for the f16x3 mode only");
+    static_assert(VAR == 0 || MF == 2 || (MF == 0 && VAR == VAR_RESREG), "the A/B variants belong to the two-cout-tile kernel");
+    constexpr int SWZ = (VAR & VAR_SWZ) ? 1 : 0;
     // MF: 0 = 16x16x32, a wave = one cout tile x half of the position tiles; 1 = 32x32x16; 2 = 16x16x32, a wave = two cout
     // tiles x a quarter of the position tiles (conv_lds_h3_c2)
     constexpr int STRIDE = MF == 1 ? C + 4 : C + 8; // dwords per LDS row (see conv_lds_h3_32 for the 32x32x16 tiling's choice)
@@ -909,7 +1029,9 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
                             ol.h[q] = __builtin_convertvector(xx - __builtin_convertvector(hh, f2v), h2v);
                         }
                         if (row < R) {
-                            _Float16 *ph = dsth + (size_t)row * (S4 * 8) + cto * 16 + gg * 4;
+                            int col = cto * 16 + gg * 4;
+                            if constexpr (SWZ) col = (((cto * 2 + (gg >> 1)) ^ ((jr >> 2) & 3)) * 8) + (gg & 1) * 4;
+                            _Float16 *ph = dsth + (size_t)row * (S4 * 8) + col;
                             *reinterpret_cast<u32x2 *>(ph) = oh.u;
                             *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
                         }
@@ -936,7 +1058,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
 #pragma unroll
                 for (int k = 0; k < 27; k++) acc += in27[k] * *reinterpret_cast<const f32x4 *>(wl + k * C + co);
 #pragma unroll
-                for (int e = 0; e < 4; e++) act_store<C, PREC, STRIDE>(X, row, co + e, fmaxf(acc[e], 0.0f), ovf);
+                for (int e = 0; e < 4; e++) act_store<C, PREC, STRIDE, SWZ>(X, row, co + e, fmaxf(acc[e], 0.0f), ovf);
             }
         }
         }
@@ -990,7 +1112,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         WPre pre2[2];
         (void)pre2;
         if (NL > 0) {
-            if constexpr (MF == 2) wpre_load_c2<C>(pre2, tw4, wave, lane);
+            if constexpr (MF == 2) { if constexpr (!(VAR & VAR_WLDS)) wpre_load_c2<C>(pre2, tw4, wave, lane); }
 #ifdef DBAZ_DEBUG
             else if constexpr (MF == 1) wpre_load32<C>(pre, tw4, wave, lane);
 #endif
@@ -999,6 +1121,60 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         unsigned long long stamps[4] = {0, 0, 0, 0};
         unsigned long long tb0 = 0, tb1 = 0, tk0 = 0, tk1 = 0;
         (void)tb0; (void)tb1; (void)tk0; (void)tk1;
+        f32x4 res[2][NTA]; // the residual stream of this wave's outputs (activation-scaled f32): conv_lds_h3_c2 / conv_lds_h3
+        (void)res;
+        if constexpr (MF == 0 && (VAR & VAR_RESREG) != 0) {
+            // block 0's input = conv0's output, which other waves wrote: decode this wave's share once (one cout tile, wave & 3)
+            const _Float16 *xh = reinterpret_cast<const _Float16 *>(X4);
+            const int ctc = wave & 3;
+            if (ctc < C / 16) {
+#pragma unroll
+                for (int t = 0; t < NTA; t++) {
+                    const int row = min((tbase + t) * 16 + jrow, R - 1);
+                    const _Float16 *ph = xh + (size_t)row * (S4 * 8) + ctc * 16 + gq * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) res[0][t][e] = (float)ph[e] + (float)ph[C + e];
+                }
+            }
+        }
+        if constexpr (MF == 2 && (VAR & VAR_RESREG) != 0) {
+            // block 0's input = conv0's output, which other waves wrote: decode this wave's share once
+            const _Float16 *xh = reinterpret_cast<const _Float16 *>(X4);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int ctc = (wave & 1) * 2 + c;
+                int col = ctc * 16 + gq * 4;
+                if constexpr (SWZ) col = (((ctc * 2 + (gq >> 1)) ^ ((jrow >> 2) & 3)) * 8) + (gq & 1) * 4;
+#pragma unroll
+                for (int t = 0; t < NTA; t++) {
+                    const int row = min((tbase + t) * 16 + jrow, R - 1);
+                    const _Float16 *ph = xh + (size_t)row * (S4 * 8) + col;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) res[c][t][e] = (float)ph[e] + (float)ph[C + e];
+                }
+            }
+        }
+        f32x4 *wring = nullptr; // VAR_WLDS: two-slot weight ring behind the two activation images
+        if constexpr (MF == 2 && (VAR & VAR_WLDS) != 0) {
+            wring = Y4 + img_units;
+            if (NL > 0) {
+                const f32x4 *d0 = tw4 + ((size_t)(wave >> 1) * (9 * (C / 32)) * 2 + (wave & 1)) * 64 + lane;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(wring + (size_t)wave * 64));
+                glds16(d0, dst);
+                glds16(d0 + 128, dst + WRING_UNITS * 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            {   // layer 0's step 0 out of slot 0, by every wave, before any wave's step 0 refills the slot
+                const f32x4 *r0 = wring + (size_t)((wave & 1) * 2) * 2 * 64 + lane;
+                pre2[0].h0 = r0[0]; pre2[0].l0 = r0[64]; pre2[1].h0 = r0[128]; pre2[1].l0 = r0[192];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+        if constexpr ((VAR & VAR_PRIO) != 0) {
+            if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+        }
         STAMP(tk0);
         tL0 = tk0;
         for (int l = 0; l < NL; l++) {
@@ -1006,7 +1182,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             f32x4 *dst = (l & 1) ? X4 : Y4;
             const f32x4 *nxt = l + 1 < NL ? tw4 + (size_t)(l + 1) * wl : nullptr;
             if constexpr (MF == 2) {
-                conv_lds_h3_c2<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre2, nxt, stamps);
+                conv_lds_h3_c2<C, NTA, VAR>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre2, nxt, res, stamps, wring);
 #ifdef DBAZ_DEBUG
             } else if constexpr (MF && NTB > 0) {
                 if (first) conv_lds_h3_32<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
@@ -1015,8 +1191,9 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
                 conv_lds_h3_32<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre, nxt, stamps);
 #endif
             } else {
-                if (first) conv_lds_h3<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
-                else if constexpr (NTB > 0) conv_lds_h3<C, NTB>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, stamps);
+                constexpr bool RR = (VAR & VAR_RESREG) != 0;
+                if (first) conv_lds_h3<C, NTA, RR>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, res[0], stamps);
+                else if constexpr (NTB > 0) conv_lds_h3<C, NTB, RR>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, nullptr, nullptr, pre, nxt, reinterpret_cast<f32x4(&)[NTB]>(res[0]), stamps);
             }
             STAMP(tb0);
             __syncthreads();
@@ -1025,6 +1202,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             stamps[3] += tb1 - tb0;
 #endif
         }
+        if constexpr ((VAR & VAR_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
 #ifdef DBAZ_STAMP
         STAMP(tk1);
         tL1 = tk1;
@@ -1057,7 +1235,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             for (int t = grp; t < NT; t += ngrp) {
                 const int row = t * 16 + hj;
                 const int rr = min(row, R - 1);
-                const f32x4 *bp = X4 + (size_t)rr * S4 + hq;
+                const f32x4 *bp = X4 + (size_t)rr * S4 + (SWZ ? (hq ^ ((rr >> 2) & 3)) : hq);
                 f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
@@ -1097,7 +1275,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             const int row = tid;
             float xr[C];
 #pragma unroll
-            for (int c = 0; c < C; c++) xr[c] = act_load<C, PREC, STRIDE>(X, row, c);
+            for (int c = 0; c < C; c++) xr[c] = act_load<C, PREC, STRIDE, SWZ>(X, row, c);
             const int sidx = row / HW, p = row - sidx * HW;
             for (int oc = 0; oc < OC; oc++) {
                 float acc = a.hb[oc];
@@ -1146,7 +1324,7 @@ __device__ __forceinline__ int tower_split(const TowerArgs &a, int n, int &n_ful
     return 0;
 }
 
-template <int C, int NTA, int NTB, int PREC, int MF = 0>
+template <int C, int NTA, int NTB, int PREC, int MF = 0, int VAR = 0>
 __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1195,7 +1373,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
             const int nr = n_redo;
             for (int r = 0; r < nr; r++) {
                 const int s0 = redo_grp[r] * S;
-                tower_group<C, NTA, NTB, PREC, MF>(g, a, lds, S, s0, min(S, n - s0));
+                tower_group<C, NTA, NTB, PREC, MF, VAR>(g, a, lds, S, s0, min(S, n - s0));
                 __syncthreads();
             }
             return;
@@ -1203,13 +1381,13 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
     }
     const int s0 = first_sample + blockIdx.x * S;
     if (s0 >= limit) return;
-    tower_group<C, NTA, NTB, PREC, MF>(g, a, lds, S, s0, min(S, limit - s0));
+    tower_group<C, NTA, NTB, PREC, MF, VAR>(g, a, lds, S, s0, min(S, limit - s0));
 }
 
 // The remainder of a batch in ONE launch (f16x3, one-cout-tile tiling): the workgroups pick the size the split asks for --
 // <2,2> / <4,4> / <5,5> / <7,6> tiles per wave half, S_small / S_mid / S_big / S_huge samples -- instead of four launches of
 // which three leave at once (5 us each: 1 % of a 6x6 step, 4 % of a 3x3 step).
-template <int C>
+template <int C, int RR = 0>
 __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_rem(Geo g, TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1221,10 +1399,13 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_tower_rem(Geo g, TowerArgs 
     const int s0 = n_full + blockIdx.x * S;
     if (s0 >= n) return;
     const int ns = min(S, n - s0);
-    if (mode == 1) tower_group<C, 2, 2, 1, 0>(g, a, lds, S, s0, ns);
-    else if (mode == 2) tower_group<C, 4, 4, 1, 0>(g, a, lds, S, s0, ns);
-    else if (mode == 3) tower_group<C, 5, 5, 1, 0>(g, a, lds, S, s0, ns);
-    else tower_group<C, 7, 6, 1, 0>(g, a, lds, S, s0, ns);
+    // RR = 1: the bodies beside a two-cout-tile main launch keep the residual stream in registers like it (the 7-tile body then
+    // spills 28 registers around its main loop: +2 % on that body, which as a remainder round still beats a partial round of the
+    // main launch by 8 %; where the 7-tile body IS the main launch -- 9x9 -- every body of the geometry stays RR = 0)
+    if (mode == 1) tower_group<C, 2, 2, 1, 0, RR>(g, a, lds, S, s0, ns);
+    else if (mode == 2) tower_group<C, 4, 4, 1, 0, RR>(g, a, lds, S, s0, ns);
+    else if (mode == 3) tower_group<C, 5, 5, 1, 0, RR>(g, a, lds, S, s0, ns);
+    else tower_group<C, 7, 6, 1, 0, RR>(g, a, lds, S, s0, ns);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1340,8 +1521,9 @@ __global__ void __launch_bounds__(CONV_THREADS, 1) k_simple_trunk(Geo g, SimpleA
             const f32x4 *tw4 = reinterpret_cast<const f32x4 *>(a.tw);
             WPre pre;
             wpre_load<C>(pre, tw4 + (size_t)l * wl16, wave, lane);
+            f32x4 res_unused[NTH]; // (no residual connections in SimpleNN)
             conv_lds_h3<C, NTH>(src, dst, tw4 + (size_t)l * wl16, a.tb + l * C, a.tosc[l], vm, rowbase, zu, W, R, wave, lane, 0,
-                                ovf, tbase, a.ts + l * C, a.tt + l * C, pre, nullptr);
+                                ovf, tbase, a.ts + l * C, a.tt + l * C, pre, nullptr, res_unused);
         }
         __syncthreads();
     }
@@ -1585,7 +1767,13 @@ NNState *nn_create(const Geo &g, int max_batch, int precision, bool no_fallback)
     // A/B tilings (debug build): 2 = the arithmetic of 1 on the 32x32x16 MFMA; 3 / 4 = two / one cout tile(s) per wave explicitly
     // (1, 3 and 4 give bit-identical results)
     nn->want_mf32 = precision == 2;
-    nn->want_c2 = precision == 1 || precision == 3;
+    nn->want_c2 = precision == 1 || precision == 3 || precision >= 5;
+    // 5..9: the two-cout-tile kernel with VAR = 1 (register residual), 2 (swizzled columns), 3 (both), 8 (s_setprio), 11 (all)
+    // 10, 11: the weight fragments through an LDS ring (VAR 4), and that with the register residual (VAR 5)
+    // 12, 13: VAR 5 with every lo half zero (timing bound, wrong results) / with 8-bit lo halves
+    static const int var_of[] = {1, 2, 3, 8, 11, 4, 5, 21, 37};
+    if (precision == 3) nn->variant = 0; // round 2's kernel: weights L2 -> registers per wave, residual decoded from LDS
+    if (precision >= 5 && precision <= 13) nn->variant = var_of[precision - 5];
 #endif
     return nn;
 }
@@ -1723,6 +1911,8 @@ static bool pack_conv(NNState *nn, const std::string &conv, const std::string &b
                             float v = (float)((double)(*w)[((size_t)co * Cr + ci) * 9 + tap] * s[co] * wscale);
                             _Float16 h = (_Float16)v;
                             _Float16 l = (_Float16)(v - (float)h);
+                            if (nn->variant & 16) l = (_Float16)0.0f;            // debug variants VAR_LO0 / VAR_LO8 (see conv_lds_h3_c2)
+                            if (nn->variant & 32) { unsigned short u; memcpy(&u, &l, 2); u &= 0xFFF8; memcpy(&l, &u, 2); }
                             size_t base = ((((size_t)ct * 9 + tap) * KS + ks) * 2) * 64 * 8;
                             hp[base + (size_t)lane * 8 + e] = h;
                             hp[base + 64 * 8 + (size_t)lane * 8 + e] = l;
@@ -1779,6 +1969,11 @@ static hipError_t tower_inst_mf(NNState *nn, hipStream_t s, const TowerArgs &ta,
 // the remainder launch (f16x3, geometries whose main one-cout-tile instantiation is <7,6>)
 static hipError_t tower_dispatch_rem(NNState *nn, hipStream_t s, const TowerArgs &ta, int grid, bool attr_only)
 {
+    if (nn->c2) { // beside the two-cout-tile main launch: register-resident residual in every body
+        if (attr_only) return hipFuncSetAttribute((const void *)k_tower_rem<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds);
+        hipLaunchKernelGGL((k_tower_rem<64, 1>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds, s, nn->g, ta);
+        return hipSuccess;
+    }
 #define REM_CASE(CC)                                                                                                                  \
     case CC:                                                                                                                          \
         if (attr_only) return hipFuncSetAttribute((const void *)k_tower_rem<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds); \
@@ -1792,18 +1987,38 @@ static hipError_t tower_dispatch_rem(NNState *nn, hipStream_t s, const TowerArgs
 }
 
 // two cout tiles per wave (C = 64): nt position tiles per wave, 4 tile groups
-static hipError_t tower_dispatch_c2(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt, int grid, bool attr_only)
+template <int VAR>
+static hipError_t tower_dispatch_c2v(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt, int grid, bool attr_only)
 {
 #define C2_CASE(NT)                                                                                                                   \
     case NT:                                                                                                                          \
-        if (attr_only) return hipFuncSetAttribute((const void *)k_tower<64, NT, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds_c2); \
-        hipLaunchKernelGGL((k_tower<64, NT, 0, 1, 2>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds_c2, s, nn->g, ta);                \
+        if (attr_only) return hipFuncSetAttribute((const void *)k_tower<64, NT, 0, 1, 2, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds_c2); \
+        hipLaunchKernelGGL((k_tower<64, NT, 0, 1, 2, VAR>), dim3(grid), dim3(CONV_THREADS), nn->conv_lds_c2, s, nn->g, ta);           \
         return hipSuccess;
     switch (nt) {
         C2_CASE(1) C2_CASE(2) C2_CASE(3) C2_CASE(4)
     default: return hipErrorInvalidValue;
     }
 #undef C2_CASE
+}
+#define VAR_SHIPPED (VAR_RESREG | VAR_WLDS) // the main launch of the release library
+static hipError_t tower_dispatch_c2(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt, int grid, bool attr_only)
+{
+#ifdef DBAZ_DEBUG // A/B variants of the main launch (nn_precision 3, 5..13 of the debug build)
+    switch (nn->variant) {
+    case 0: return tower_dispatch_c2v<0>(nn, s, ta, nt, grid, attr_only);
+    case 1: return tower_dispatch_c2v<1>(nn, s, ta, nt, grid, attr_only);
+    case 2: return tower_dispatch_c2v<2>(nn, s, ta, nt, grid, attr_only);
+    case 3: return tower_dispatch_c2v<3>(nn, s, ta, nt, grid, attr_only);
+    case 8: return tower_dispatch_c2v<8>(nn, s, ta, nt, grid, attr_only);
+    case 11: return tower_dispatch_c2v<11>(nn, s, ta, nt, grid, attr_only);
+    case 4: return tower_dispatch_c2v<4>(nn, s, ta, nt, grid, attr_only);
+    case 21: return tower_dispatch_c2v<21>(nn, s, ta, nt, grid, attr_only);
+    case 37: return tower_dispatch_c2v<37>(nn, s, ta, nt, grid, attr_only);
+    default: break;
+    }
+#endif
+    return tower_dispatch_c2v<VAR_SHIPPED>(nn, s, ta, nt, grid, attr_only);
 }
 #ifdef DBAZ_DEBUG
 static hipError_t tower_dispatch_mf(NNState *nn, hipStream_t s, const TowerArgs &ta, int nt2, int grid, bool attr_only)
@@ -2212,20 +2427,25 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
     if (nn->c2 && C == 64) {
         int Sc = MAXROWS / HW;
         if (Sc > 16) Sc = 16;
-        while (Sc > 1 && lds_bytes(Sc) > lds_budget) Sc--;
+        // (the shipped variant keeps a two-slot weight ring of 16 KB behind the images; 1.1 KB of static LDS besides)
+        const size_t ring = (nn->variant & 4) ? (size_t)2 * 512 * 16 : 0, budget_c2 = (size_t)160 * 1024 - 1536;
+        while (Sc > 1 && lds_bytes(Sc) + ring > budget_c2) Sc--;
         nn->S_c2 = Sc;
         nn->NT_c2 = ((Sc * HW + 15) / 16 + 3) / 4;           // tiles per wave (4 groups)
-        nn->conv_lds_c2 = lds_bytes(Sc);
+        nn->conv_lds_c2 = lds_bytes(Sc) + ring;
         // worth it only where its 4 x NT_c2 tiles are filled about as well as the one-cout-tile kernel's NT (9x9: 200 of 256
         // rows against 200 of 208)
         const double fill_c2 = (double)Sc * HW / (64.0 * nn->NT_c2), fill_1 = (double)nn->S * HW / (16.0 * nn->NT);
         if (fill_c2 < 0.97 * fill_1) nn->c2 = 0;
-        if (nn->NT_c2 < 1 || nn->NT_c2 > 4) nn->c2 = 0;
+        if (nn->NT_c2 < 1 || nn->NT_c2 > 4 || lds_bytes(Sc) + ring > budget_c2) nn->c2 = 0;
     } else {
         nn->c2 = 0;
     }
     hipError_t he = tower_dispatch(nn, nullptr, TowerArgs(), nn->NTT, 0, true);
     nn->use_rem = (nn->precision == 1 && nn->NTT == 7 && C >= 32 && !nn->mf32) ? 1 : 0;
+    // the two-cout-tile main launch keeps the residual stream in registers; its remainder bodies must round the same way, and
+    // those live in k_tower_rem<64, 1>: no remainder launch, no two-cout-tile main launch
+    if (!nn->use_rem) nn->c2 = 0;
     if (he == hipSuccess && nn->use_rem) he = tower_dispatch_rem(nn, nullptr, TowerArgs(), 0, true);
     if (he == hipSuccess && nn->c2) he = tower_dispatch_c2(nn, nullptr, TowerArgs(), nn->NT_c2, 0, true);
 
@@ -2286,10 +2506,6 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
         // as role 4) -- or stays with this launch if it is more than such a round holds
         ta.S_main = ta.S = nn->S_c2; ta.S_huge = nn->S;
         (void)tower_dispatch_c2(nn, s, ta, nn->NT_c2, (max_n + nn->S_c2 - 1) / nn->S_c2, false);
-        if (!nn->use_rem) {
-            ta.role = 4; ta.S = nn->S;
-            (void)tower_dispatch(nn, s, ta, nn->NTT, nn->cus, false);
-        }
     }
     if (nn->mf32 && !nn->c2) {
         // 32x32x16 tiling: main launch + one tail launch of half-size workgroups (same split rule, derived from n on the device)
