@@ -184,6 +184,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     if (cfg->nn_precision < 0 || cfg->nn_precision > 1) return set_error(nullptr, DBAZ_EINVAL, "nn_precision must be 0 (exact f32) or 1 (f16x3)");
 #endif
     if (cfg->eval_round < -1 || cfg->eval_defer_max < 0) return set_error(nullptr, DBAZ_EINVAL, "bad eval_round / eval_defer_max");
+    if (cfg->selfplay_pending && cfg->max_pending_evals <= 1) return set_error(nullptr, DBAZ_EINVAL, "selfplay_pending needs max_pending_evals > 1");
     int ndev = 0;
     hipError_t herr = hipGetDeviceCount(&ndev);
     if (herr != hipSuccess || ndev <= 0)
@@ -245,7 +246,9 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     sc.evaluator = cfg->evaluator; sc.seed = cfg->seed;
     sc.match_play = cfg->match_play ? 1 : 0; sc.evaluator2 = cfg->evaluator2;
     sc.pending = cfg->max_pending_evals > 1 ? cfg->max_pending_evals : 1;
-    sc.virtual_visits = 1;
+    // self-play in waves follows the reference's bookkeeping (visits added at backup, mcts.py:121-126); the single-tree search
+    // of players.AZPlayer defaults to counted virtual visits (dbaz_set_pending changes either)
+    sc.virtual_visits = cfg->selfplay_pending ? 0 : 1;
 
     TreeBufs &B = e->B;
     memset(&B, 0, sizeof(B));
@@ -605,12 +608,17 @@ static hipEvent_t next_event(dbaz_engine *e)
 
 // one WAVE of up to K simulations for every searching tree (max_pending_evals = K > 1): K sequential selections with
 // virtual loss per tree, one batched evaluation of all their leaves, expand + backup in selection order
-static int sim_wave(dbaz_engine *e)
+// with_driver (self-play with dbaz_config.selfplay_pending: every search of a game runs in these waves, the reference's
+// self_play.py:27-30 with max_async_searches = K): the driver pass -- move choice, row emission, re-root, next search's root
+// preparation -- runs first, on the same stream; a slot it starts takes its first wave in this very step
+static int sim_wave(dbaz_engine *e, bool with_driver)
 {
     hipStream_t s = e->stream;
     const bool use_nn = e->sc.evaluator == DBAZ_EVAL_RESNET || e->sc.evaluator == DBAZ_EVAL_SIMPLENN;
     e->sc.step = (int)(e->steps & 0x3FFFFFFF) + 1;
     e->sc.driver_concurrent = 0;
+    e->sc.eval_round = 0;
+    if (with_driver) tree_launch_advance_auto(s, e->g, e->sc, e->B, e->n_slots);
     tree_launch_select_multi(s, e->g, e->sc, e->B, e->n_slots);
     if (use_nn) {
         nn_forward(e->nns[0], s, e->B.feat_m, e->B.list_m, e->B.n_eval, e->n_slots * e->B.kmax, e->B.evalP_m, e->B.evalV_m, e->g.AS, nullptr, nullptr);
@@ -625,7 +633,7 @@ static int sim_wave(dbaz_engine *e)
 // one simulation step for every searching slot
 static int sim_step(dbaz_engine *e, bool with_driver)
 {
-    if (e->B.kmax > 1 && !with_driver) return sim_wave(e);
+    if (e->B.kmax > 1 && (!with_driver || e->cfg.selfplay_pending)) return sim_wave(e, with_driver);
     hipStream_t s = e->stream;
     auto is_nn = [](int ev) { return ev == DBAZ_EVAL_RESNET || ev == DBAZ_EVAL_SIMPLENN; };
     const bool use_nn = is_nn(e->sc.evaluator);

@@ -1070,7 +1070,7 @@ __global__ void __launch_bounds__(WAVE) k_expand_backup_multi(Geo g, SearchCfg c
     __shared__ float ldsf[DBAZ_MAX_A];
     __shared__ double ldsd[DBAZ_MAX_A];
     const int slot = blockIdx.x, lane = threadIdx.x;
-    if (slot == 0 && lane == 0) { B.n_eval[0] = 0; B.n_eval[1] = 0; }
+    if (slot == 0 && lane == 0) { B.n_eval[0] = 0; B.n_eval[1] = 0; B.drv_count[0] = 0; } // (drv_count: self-play in waves)
     Slot *S = B.slots + slot;
     const int phase = S->phase;
     if (phase != PH_EXPAND_ROOT && phase != PH_SIMS) return;

@@ -28,14 +28,26 @@ def shard_games(n_games, world_size, rank):
     return first, base + (1 if rank < extra else 0)
 
 
-def engine_kwargs_from_params(params):
-    """Pull the hot-path knobs out of a reference-style params dict (configuration.py:82-100)."""
+def engine_kwargs_from_params(params, async_searches=False):
+    """Pull the hot-path knobs out of a reference-style params dict (configuration.py:82-100).
+
+    async_searches: the reference runs every self-play search with `max_async_searches` simulations of the ONE tree in flight
+    (self_play.py:27-30, configuration.py:99: 64), only to fill a GPU batch from a single game -- 98 % of those leaves are
+    duplicates.  Here the batch comes from thousands of concurrent games, so the default is the sequential search per
+    game (max_pending_evals = 1: the semantics of every parity path).  async_searches=True honours the knob instead: every search
+    of every game runs in waves of self_play.mcts.max_async_searches simulations with the reference's bookkeeping
+    (dbaz_config.selfplay_pending; equal to the reference's own UCT_search(..., max_pending_evals=K) under an evaluator that
+    suspends once per call, tests/test_hip_pending.py)."""
     sp = _get(params, "self_play")
     m = _get(sp, "mcts")
     noise = _get(sp, "noise", [0.0, 0.0])
-    return dict(mcts_num_read=int(_get(m, "mcts_num_read", 800)), cpuct=tuple(_get(m, "mcts_cpuct", (1.25, 19652))),
-                noise=(float(noise[0]), float(noise[1])), temperature=dict(_get(m, "temperature", {0: 1.0})),
-                reuse_tree=bool(_get(sp, "reuse_mcts_tree", True)))
+    kw = dict(mcts_num_read=int(_get(m, "mcts_num_read", 800)), cpuct=tuple(_get(m, "mcts_cpuct", (1.25, 19652))),
+              noise=(float(noise[0]), float(noise[1])), temperature=dict(_get(m, "temperature", {0: 1.0})),
+              reuse_tree=bool(_get(sp, "reuse_mcts_tree", True)))
+    k = int(_get(m, "max_async_searches", 1) or 1)
+    if async_searches and k > 1:
+        kw.update(max_pending_evals=k, selfplay_pending=True, transposition_cache=False)
+    return kw
 
 
 def samples_to_dataframe(s, generation, rows, cols, with_features=True):
@@ -106,7 +118,7 @@ def write_dataset(file_name, key, df):
 
 
 def generate_games(hdf_file_name, generation, nn_class, n_games, params, n_workers=None, games_per_workers=10,
-                   rows=None, cols=None, n_slots=None, device=0, dist=None, nn_precision=None):
+                   rows=None, cols=None, n_slots=None, device=0, dist=None, nn_precision=None, async_searches=False):
     """Reference: self_play.generate_games (self_play.py:291-306) called from coach.selfplay
     (coach.py:27-29).  Plays n_games with generation-1's weights (random init for generation 0,
     self_play.py:187-190) and appends the samples (+ `training` = 0) to key "fresh".
@@ -116,7 +128,9 @@ def generate_games(hdf_file_name, generation, nn_class, n_games, params, n_worke
     and EVERY rank builds the DataFrame of all n_games games -- the reference's workers all append
     to the one HDF file (self_play.py:264-265); here rank 0 writes it.
     nn_precision: None = the engine's default for the network (ResNetZero: 1, the f16x3 mode every published number of this
-    repository is measured in; 0 = exact f32 MFMA, 2.6x slower)."""
+    repository is measured in; 0 = exact f32 MFMA, 2.6x slower).
+    async_searches: honour params.self_play.mcts.max_async_searches (see engine_kwargs_from_params; default: sequential search
+    per game, batching across games)."""
     from .engine import Engine
     game = _get(params, "game")
     if rows is None:
@@ -130,7 +144,7 @@ def generate_games(hdf_file_name, generation, nn_class, n_games, params, n_worke
         model.load_parameters(generation - 1)
     # Philox streams are keyed by (seed, game, ply): sharding does not change a game
     eng = Engine(rows, cols, n_slots, evaluator=model.kind, device=device, seed=generation * 1000003,
-                 nn_precision=nn_precision, **engine_kwargs_from_params(params))
+                 nn_precision=nn_precision, **engine_kwargs_from_params(params, async_searches))
     try:
         if model.kind in ("resnet", "simplenn"):
             eng.load_state_dict(model.state_dict(), model.kind, **model.shape)

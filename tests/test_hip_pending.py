@@ -297,3 +297,72 @@ def test_pending_waves_with_the_network_vs_oracle_fed_by_it(K):
                 trees[s].advance(int(moves[s]), True)
         e.advance(moves, True)
     e.close()
+
+
+def _fact_reads(n_valid, sims):
+    """n_searches = min(4 * factorial(nb_valid_moves), mcts_num_read), self_play.py:64-65"""
+    f = 4.0
+    for i in range(2, n_valid + 1):
+        f *= i
+        if f > sims:
+            break
+    return int(f) if f < sims else sims
+
+
+@pytest.mark.parametrize("rows,cols,n_slots,n_games,sims,K,reuse", [(3, 3, 8, 20, 60, 8, True), (6, 6, 6, 6, 100, 8, True),
+                                                                   (3, 3, 4, 8, 40, 64, False), (2, 3, 5, 10, 30, 3, True)])
+def test_selfplay_driver_in_waves_vs_oracle_wave_search(rows, cols, n_slots, n_games, sims, K, reuse):
+    """dbaz_config.selfplay_pending (self_play.py:27-30: every self-play search runs with max_async_searches simulations of the
+    tree in flight): the DRIVER -- dbaz_run with slot refill, 4*n! rule, temperature sampling, re-rooting, row emission -- steps
+    every game in waves of K through k_select_multi / k_expand_backup_multi with the reference's bookkeeping.  Each finished game is
+    replayed move by move by the oracle's wave search (ob_uct_search_pending, pinned to the reference's own
+    UCT_search(..., max_pending_evals=K) by tests/golden/pending.npz), teacher-forced with the moves the device sampled: visit
+    vectors, pi, q, TreeStats, features and z of every row must be bit-identical."""
+    from dotsboxesaz_amd.engine import Engine
+    d = O.dims(rows, cols)
+    e = Engine(rows, cols, n_slots, mcts_num_read=sims, noise=(0.0, 0.0), reuse_tree=reuse, evaluator="formula", seed=3,
+               max_pending_evals=K, selfplay_pending=True)
+    e.selfplay_start(n_games, 0)
+    e.run()
+    c = e.counters()
+    assert c["games_finished"] == n_games and c["error_slots"] == 0
+    got = e.fetch_samples()
+    e.close()
+    ev = O.Evaluator(0)
+    n_exp = 0
+    for gidx in range(n_games):
+        sel = np.nonzero(got["game_idx"] == gidx)[0]
+        assert list(got["move_idx"][sel]) == list(range(len(sel)))
+        t = O.Tree(d, O.new_state(d))
+        for r in sel:
+            st = t.state
+            nv = int(O.valid_moves(d, st).sum())
+            reads = _fact_reads(nv, sims)
+            vis = t.search(reads, ev, max_pending=K)
+            md, ts, tc, q = t.stats()
+            n_exp += reads
+            assert np.array_equal(got["visits"][r], vis), (gidx, r)
+            assert np.array_equal(got["x"][r], O.features(d, st).ravel()), (gidx, r)
+            assert (int(got["max_deepness"][r]), int(got["tree_size"][r]), int(got["terminal_count"][r])) == (md, ts, tc), (gidx, r)
+            assert np.float32(got["q_value"][r]).view(np.uint32) == np.float32(q).view(np.uint32), (gidx, r)
+            assert got["player"][r] == st.to_play
+            s = vis.sum()
+            assert np.array_equal(got["pi"][r], vis.astype(np.float64) / (s if s else 1.0))
+            t.advance(int(got["played"][r]), reuse)
+        assert t.is_terminal
+        # z: +z_T for rows whose to_play is the terminal state's just_played, -z_T otherwise (self_play.py:105-112)
+        term = t.state
+        zt = O.get_result(term)
+        for r in sel:
+            exp = zt if got["player"][r] == term.just_played else -zt
+            assert int(got["z"][r]) == exp, (gidx, r)
+    assert n_exp > 0
+
+
+def test_engine_kwargs_honour_max_async_searches_only_on_request():
+    from dotsboxesaz_amd.self_play import engine_kwargs_from_params
+    params = {"self_play": {"reuse_mcts_tree": True, "noise": [0.8, 0.25],
+                            "mcts": {"mcts_num_read": 20, "mcts_cpuct": [1.25, 19652], "temperature": {0: 1.0}, "max_async_searches": 64}}}
+    assert "max_pending_evals" not in engine_kwargs_from_params(params)
+    kw = engine_kwargs_from_params(params, async_searches=True)
+    assert kw["max_pending_evals"] == 64 and kw["selfplay_pending"] is True
