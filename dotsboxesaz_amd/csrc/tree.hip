@@ -578,8 +578,10 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
         return -1;
     if (cfg.eval_round > 0 && S->pending) {
         // the leaf of an earlier step whose evaluation was put off (full rounds only): path, leaf and features are still in place.
-        // It takes its place in the list at once -- ahead of every leaf that is still being selected, so it cannot be put off
-        // again (the workgroup's batched append below happens after the slowest of its 16 descents)
+        // It asks for its place in the list at once, i.e. usually ahead of the leaves that are still being selected (a workgroup's
+        // batched append below happens after the slowest of its 16 descents).  That is an ordering tendency, not a guarantee: the
+        // append is an atomicAdd racing with other workgroups', so a leaf CAN land behind the cut again and wait one more step.
+        // Nothing depends on it -- a put-off leaf only completes its simulation later; the game plays the same moves.
         if (lane == 0) {
             S->sel_step = cfg.step;
             const int pos = atomicAdd(B.n_eval, 1);

@@ -289,8 +289,20 @@ class Engine:
             self._ck(self._L.dbaz_run(self.h, int(max_steps)))
             c = self.counters()
             if max_steps or c["active_slots"] == 0 or c["blocked_slots"] < c["active_slots"]:
+                self._warn_pool_resets(c)
                 return
             self._drained.append(self._fetch_once())
+
+    def _warn_pool_resets(self, c):
+        """The reference's trees are unbounded; a slot's node pool is not: a move whose reused subtree would not leave
+        mcts_num_read + 2 nodes free starts from a fresh root instead (counters()["pool_resets"]).  Said once per handle."""
+        n = int(c.get("pool_resets", 0))
+        if n and not getattr(self, "_warned_resets", False):
+            import warnings
+            self._warned_resets = True
+            warnings.warn("%d of %d moves were searched from a fresh root because the reused subtree did not leave mcts_num_read + 2 "
+                          "nodes of the slot's pool free: raise nodes_per_slot (now %d) to keep the reference's tree reuse on every move"
+                          % (n, int(c.get("moves_played", 0)), self.nodes_per_slot))
 
     def sync(self):
         self._ck(self._L.dbaz_sync(self.h))

@@ -158,11 +158,16 @@ class NeuralNetWrapper:
     async def __call__(self, X):
         return await self.predict(X)
 
-    def train(self, train_dataset, val_dataset, writer, generation):
+    def train(self, train_dataset, val_dataset, writer, generation, hip_validation=True):
         """nn.py:175-274.  The optimizer step runs in torch on ROCm (see train.py); batches come from
         HBM when the datasets are train_data.ReplayDataset objects.  The trained weights are pushed
-        back into the HIP engine so that the next self-play generation uses them."""
+        back into the HIP engine so that the next self-play generation uses them.
+        hip_validation: the validation passes (nn.py:223-246, model.train(False)) run on the HIP inference engine -- the same
+        eval-mode network the reference evaluates, log p = log(softmax) instead of log_softmax: |d log p| <= 1e-4 wherever
+        p >= 1e-3, validation losses within 1e-4 of torch's eval forward (tests/test_hip_coach.py) -- and fall back to torch's
+        forward for a batch the engine rejects (SimpleNN in f16x3 has no exact-f32 safety net).  False: torch's forward."""
         from . import train as T
+        from . import _lib
         import torch
 
         def eval_forward(model):
@@ -170,13 +175,16 @@ class NeuralNetWrapper:
             self.engine.load_state_dict(model.state_dict(), model.kind, **model.shape)
 
             def fwd(boards):
-                p, v = self.engine.predict(boards.detach().cpu().numpy())
+                try:
+                    p, v = self.engine.predict(boards.detach().cpu().numpy())
+                except _lib.DbazError:  # e.g. an activation beyond f16's range without a safety net: torch evaluates this batch
+                    return T.training_forward(model, boards)
                 lp = torch.log(torch.from_numpy(p).clamp_min(1e-38)).to(boards.device)
                 return lp, torch.from_numpy(v).to(boards.device)
             return fwd
 
         last = T.train(self.model, self.params, train_dataset, val_dataset, writer, generation,
-                       device="cuda:%d" % self.engine.cfg.device, eval_forward=eval_forward)
+                       device="cuda:%d" % self.engine.cfg.device, eval_forward=eval_forward if hip_validation else None)
         self.model.to("cpu")
         self.set_model(self.model)
         return last
