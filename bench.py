@@ -430,7 +430,7 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "simplenn", "formula", "uniform"])
-    ap.add_argument("--precision", type=int, default=1, choices=list(range(14)),
+    ap.add_argument("--precision", type=int, default=1, choices=list(range(15)),
                     help="0 = exact f32 MFMA; 1 = f16x3 error-compensated MFMA (f32-grade, default); 2 / 3 / 4 = A/B tilings of the "
                          "f16x3 layer, debug build only (DBAZ_LIB=dotsboxesaz_amd/libdbaz_hip_debug.so; EXPERIMENTS.md)")
     ap.add_argument("--debug-flags", type=int, default=0, help="dbaz_config.debug_flags (1 = early join, 2 = no f32 fallback launch)")

@@ -179,7 +179,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     if (cfg->max_pending_evals > 1 && (cfg->evaluator == DBAZ_EVAL_EXTERNAL || cfg->match_play))
         return set_error(nullptr, DBAZ_EINVAL, "max_pending_evals > 1 needs a device evaluator and no match play");
 #ifdef DBAZ_DEBUG
-    if (cfg->nn_precision < 0 || cfg->nn_precision > 13) return set_error(nullptr, DBAZ_EINVAL, "nn_precision must be in 0..13 (debug build)");
+    if (cfg->nn_precision < 0 || cfg->nn_precision > 14) return set_error(nullptr, DBAZ_EINVAL, "nn_precision must be in 0..14 (debug build)");
 #else
     if (cfg->nn_precision < 0 || cfg->nn_precision > 1) return set_error(nullptr, DBAZ_EINVAL, "nn_precision must be 0 (exact f32) or 1 (f16x3)");
 #endif

@@ -650,6 +650,155 @@ __device__ __forceinline__ void conv_lds_h3_c2(const f32x4 *__restrict__ src4, f
 #endif
 }
 
+
+#ifdef DBAZ_DEBUG // A/B record (EXPERIMENTS.md): measured 5.6 % slower per evaluation than the shipped 8-wave kernel
+// ------------------------------------------------------------------------------------
+// MF = 3: FOUR waves per workgroup, one per SIMD with the whole register file; a wave owns all four cout tiles of a quarter of
+// the position tiles (NTT tiles): 16 accumulator tiles, 48 MFMAs per K-step.  An activation fragment then feeds 12 MFMAs and a
+// weight fragment (out of the LDS ring) 12 as well: 16 ds_read_b128 per 48 MFMAs against 12 per 24 in conv_lds_h3_c2 -- a third
+// fewer LDS fragment reads per FLOP (the kernel is power-bound: EXPERIMENTS.md).  The weight ring, the register-resident residual
+// stream and the rounding are conv_lds_h3_c2's (bit-identical results).
+// ------------------------------------------------------------------------------------
+template <int C, int NTT>
+__device__ __forceinline__ void conv_lds_h3_w4(const f32x4 *__restrict__ src4, f32x4 *dst4, const f32x4 *__restrict__ wpk /*layer*/,
+                                               const float *__restrict__ bias, float oscale, const int *vm, int zbase, int W, int R,
+                                               int wave, int lane, int residual, bool &ovf_out, int tbase, f32x4 (&pre)[8],
+                                               const f32x4 *next_wpk, f32x4 (&res)[4][NTT], f32x4 *wring)
+{
+    static_assert(C == 64, "four cout tiles per wave = 64 channels");
+    constexpr int S4 = (C + 8) / 4, KS = C / 32, LO = C / 8, N = 9 * KS;
+    static_assert(N % 2 == 0, "the next layer's step 0 must land in slot 0");
+    const int jrow = lane & 15, gq = lane >> 4;
+    f32x4 acc[4][NTT];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int t = 0; t < NTT; t++) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u128h a[2][8]; // [register set][cout tile * 2 + (hi | lo)]
+    u128h bh[NTT], bl[NTT];
+    const char *sb = reinterpret_cast<const char *>(src4);
+    int ab[NTT];
+    const int rowbase = (tbase * 16 + jrow) * S4 + gq;
+    {
+        const int u0 = rowbase + (-W - 1) * S4;
+#pragma unroll
+        for (int t = 0; t < NTT; t++) ab[t] = ((vm[t] & 1) ? u0 : zbase + (u0 & 15) - t * 16 * S4) * 16;
+    }
+    // this wave's two DMA pieces of a step: the (hi, lo) fragments of cout tile `wave` (ring units (2 wave + hl) * 64 + lane)
+    const f32x4 *dsrc = wpk + (size_t)wave * N * 2 * 64 + lane;
+    const f32x4 *dnext = next_wpk ? next_wpk + (size_t)wave * N * 2 * 64 + lane : nullptr;
+    const unsigned ring_dst = __builtin_amdgcn_readfirstlane(lds_addr(wring + (size_t)wave * 2 * 64));
+    const f32x4 *rsrc = wring + lane;
+#pragma unroll
+    for (int c = 0; c < 8; c++) a[0][c].f = pre[c]; // step 0: taken out of slot 0 before the layer barrier
+#pragma unroll
+    for (int t = 0; t < NTT; t++) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4);
+#pragma unroll
+    for (int t = 0; t < NTT; t++) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + LO * 16);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        const int ni = i + 1, ntap = ni / KS, nks = ni % KS;
+        // step i + 2's pieces -> slot i & 1 (every wave took step i's fragments out of it before the last barrier)
+        if (i + 2 < N) {
+            glds16(dsrc + (size_t)(i + 2) * 128, ring_dst + (i & 1) * (WRING_UNITS * 16));
+            glds16(dsrc + (size_t)(i + 2) * 128 + 64, ring_dst + (i & 1) * (WRING_UNITS * 16) + 1024);
+        } else if (dnext) {
+            glds16(dnext + (size_t)(i + 2 - N) * 128, ring_dst + (i & 1) * (WRING_UNITS * 16));
+            glds16(dnext + (size_t)(i + 2 - N) * 128 + 64, ring_dst + (i & 1) * (WRING_UNITS * 16) + 1024);
+        }
+        if (ni < N) { // step i + 1's eight fragments out of slot (i + 1) & 1: at the head of the step, long back when the
+                      // activation reloads of this step are issued (lgkmcnt is a 4-bit counter)
+            const f32x4 *r1 = rsrc + (size_t)(ni & 1) * WRING_UNITS;
+#pragma unroll
+            for (int c = 0; c < 8; c++) a[nxt][c].f = r1[c * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // hi*hi
+#pragma unroll
+        for (int t = 0; t < NTT; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * c].h, bh[t].h, acc[c][t], 0, 0, 0);
+        if (ni < N && nks == 0) {
+            const int un = rowbase + ((ntap / 3 - 1) * W + (ntap % 3 - 1)) * S4;
+            const int zt = zbase + (un & 15);
+#pragma unroll
+            for (int t = 0; t < NTT; t++) ab[t] = (((vm[t] >> ntap) & 1) ? un : zt - t * 16 * S4) * 16;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // lo*hi; bh[t] is dead after its fourth MFMA -> reload it for the next step right there
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * c + 1].h, bh[t].h, acc[c][t], 0, 0, 0);
+            if (ni < N) bh[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // hi*lo; same for bl[t]
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * c].h, bl[t].h, acc[c][t], 0, 0, 0);
+            if (ni < N) bl[t].f = *reinterpret_cast<const f32x4 *>(sb + ab[t] + t * 256 * S4 + nks * 64 + LO * 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // end of step: this wave's DMA pieces have landed, its ring reads have returned (only the 2 NTT activation reloads issued
+        // after them may still be out) -- then every wave's have
+        if (ni < N) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(%0)" ::"n"(2 * NTT) : "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 bv[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        bv[c] = *reinterpret_cast<const f32x4 *>(bias + c * 16 + gq * 4);
+        asm volatile("" ::"v"(bv[c]));
+    }
+    if (next_wpk) { // the next layer's step 0 (slot 0: DMAed in step N - 2, fenced by that step's barrier) before the layer barrier
+#pragma unroll
+        for (int c = 0; c < 8; c++) pre[c] = rsrc[c * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    _Float16 *dsth = reinterpret_cast<_Float16 *>(dst4);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    float vmax = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int col = c * 16 + gq * 4;
+#pragma unroll
+        for (int t = 0; t < NTT; t++) {
+            const int row = (tbase + t) * 16 + jrow;
+            f32x4 v = acc[c][t] * oscale + bv[c];
+            if (residual) v += res[c][t];
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            if (residual) res[c][t] = v;
+            vmax = fmaxf(vmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            union { h2v h[2]; u32x2 u; } oh, ol;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const f2v x = {v[2 * q], v[2 * q + 1]};
+                const h2v h = __builtin_convertvector(x, h2v);
+                oh.h[q] = h;
+                ol.h[q] = __builtin_convertvector(x - __builtin_convertvector(h, f2v), h2v);
+            }
+            if (row < R) {
+                _Float16 *ph = dsth + (size_t)row * (S4 * 8) + col;
+                *reinterpret_cast<u32x2 *>(ph) = oh.u;
+                *reinterpret_cast<u32x2 *>(ph + C) = ol.u;
+            }
+        }
+    }
+    ovf_out |= vmax > F16_GUARD;
+}
+
+#endif // DBAZ_DEBUG (conv_lds_h3_w4)
+
 #ifdef DBAZ_DEBUG // A/B tiling of the debug build (tools/ab_tilings.sh); measured 2.4 % slower per evaluation (EXPERIMENTS.md)
 // ------------------------------------------------------------------------------------
 // The same f16x3 layer on v_mfma_f32_32x32x16_f16 (MF = 1).  Output tile = 32 couts x 32 positions: a wave owns one
@@ -906,7 +1055,7 @@ template <int C, int NTA, int NTB, int PREC, int MF, int VAR = 0>
 __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, float *lds, const int S, const int s0, const int ns)
 {
     static_assert(MF == 0 || PREC == 1, "the alternative tilings exist for the f16x3 mode only");
-    static_assert(VAR == 0 || MF == 2 || (MF == 0 && VAR == VAR_RESREG), "the A/B variants belong to the two-cout-tile kernel");
+    static_assert(VAR == 0 || MF >= 2 || (MF == 0 && VAR == VAR_RESREG), "the A/B variants belong to the two-cout-tile kernel");
     constexpr int SWZ = (VAR & VAR_SWZ) ? 1 : 0;
     // MF: 0 = 16x16x32, a wave = one cout tile x half of the position tiles; 1 = 32x32x16; 2 = 16x16x32, a wave = two cout
     // tiles x a quarter of the position tiles (conv_lds_h3_c2)
@@ -1078,7 +1227,8 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
     // 32x32x16: the wave pair (wave >> 1) owns tiles [(wave >> 1) * NTA, +NTA), one 32-cout tile each
     //           (NTB > 0: the older wave half takes NTA tiles per wave, the younger NTB -- tools/ab_mf32.sh)
     const bool first = wave < 4;
-    const int tbase = MF ? (NTB > 0 ? (first ? ((wave >> 1) & 1) * NTA : 2 * NTA + ((wave >> 1) & 1) * NTB) : (wave >> 1) * NTA)
+    const int tbase = MF == 3 ? wave * NTA // (four waves, a quarter of the position tiles each)
+                    : MF ? (NTB > 0 ? (first ? ((wave >> 1) & 1) * NTA : 2 * NTA + ((wave >> 1) & 1) * NTB) : (wave >> 1) * NTA)
                          : (first ? 0 : NTA);
     int vm[NTA];
 #pragma unroll
@@ -1112,7 +1262,8 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         WPre pre2[2];
         (void)pre2;
         if (NL > 0) {
-            if constexpr (MF == 2) { if constexpr (!(VAR & VAR_WLDS)) wpre_load_c2<C>(pre2, tw4, wave, lane); }
+            if constexpr (MF == 3) { }
+            else if constexpr (MF == 2) { if constexpr (!(VAR & VAR_WLDS)) wpre_load_c2<C>(pre2, tw4, wave, lane); }
 #ifdef DBAZ_DEBUG
             else if constexpr (MF == 1) wpre_load32<C>(pre, tw4, wave, lane);
 #endif
@@ -1123,7 +1274,7 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
         (void)tb0; (void)tb1; (void)tk0; (void)tk1;
         f32x4 res[2][NTA]; // the residual stream of this wave's outputs (activation-scaled f32): conv_lds_h3_c2 / conv_lds_h3
         (void)res;
-        if constexpr (MF == 0 && (VAR & VAR_RESREG) != 0) {
+        if constexpr (MF == 0 && PREC == 1 && (VAR & VAR_RESREG) != 0) {
             // block 0's input = conv0's output, which other waves wrote: decode this wave's share once (one cout tile, wave & 3)
             const _Float16 *xh = reinterpret_cast<const _Float16 *>(X4);
             const int ctc = wave & 3;
@@ -1155,6 +1306,36 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             }
         }
         f32x4 *wring = nullptr; // VAR_WLDS: two-slot weight ring behind the two activation images
+        f32x4 pre8[8];          // MF = 3: the eight weight fragments of a layer's step 0
+        f32x4 res4[4][NTA];     // MF = 3: residual stream of the wave's 4 x NTA output tiles
+        (void)pre8; (void)res4;
+        if constexpr (MF == 3) {
+            wring = Y4 + img_units;
+            if (NL > 0) {
+                const f32x4 *d0 = tw4 + (size_t)wave * (9 * (C / 32)) * 2 * 64 + lane;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(wring + (size_t)wave * 2 * 64));
+                glds16(d0, dst);
+                glds16(d0 + 64, dst + 1024);
+                glds16(d0 + 128, dst + WRING_UNITS * 16);
+                glds16(d0 + 128 + 64, dst + WRING_UNITS * 16 + 1024);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 8; c++) pre8[c] = wring[c * 64 + lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            const _Float16 *xh = reinterpret_cast<const _Float16 *>(X4);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int t = 0; t < NTA; t++) {
+                    const int row = min((tbase + t) * 16 + jrow, R - 1);
+                    const _Float16 *ph = xh + (size_t)row * (S4 * 8) + c * 16 + gq * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) res4[c][t][e] = (float)ph[e] + (float)ph[C + e];
+                }
+        }
         if constexpr (MF == 2 && (VAR & VAR_WLDS) != 0) {
             wring = Y4 + img_units;
             if (NL > 0) {
@@ -1181,6 +1362,11 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
             const f32x4 *src = (l & 1) ? Y4 : X4;
             f32x4 *dst = (l & 1) ? X4 : Y4;
             const f32x4 *nxt = l + 1 < NL ? tw4 + (size_t)(l + 1) * wl : nullptr;
+#ifdef DBAZ_DEBUG
+            if constexpr (MF == 3) {
+                conv_lds_h3_w4<C, NTA>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre8, nxt, res4, wring);
+            } else
+#endif
             if constexpr (MF == 2) {
                 conv_lds_h3_c2<C, NTA, VAR>(src, dst, tw4 + (size_t)l * wl, a.tb + l * C, a.tosc[l], vm, rowbase, zbase, W, R, wave, lane, l & 1, ovf, tbase, pre2, nxt, res, stamps, wring);
 #ifdef DBAZ_DEBUG
@@ -1325,7 +1511,7 @@ __device__ __forceinline__ int tower_split(const TowerArgs &a, int n, int &n_ful
 }
 
 template <int C, int NTA, int NTB, int PREC, int MF = 0, int VAR = 0>
-__global__ void __launch_bounds__(CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
+__global__ void __launch_bounds__(MF == 3 ? 256 : CONV_THREADS, 1) k_tower(Geo g, TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = cut_n(*a.n_dev, a.cut_round, a.cut_defer);
@@ -1771,9 +1957,10 @@ NNState *nn_create(const Geo &g, int max_batch, int precision, bool no_fallback)
     // 5..9: the two-cout-tile kernel with VAR = 1 (register residual), 2 (swizzled columns), 3 (both), 8 (s_setprio), 11 (all)
     // 10, 11: the weight fragments through an LDS ring (VAR 4), and that with the register residual (VAR 5)
     // 12, 13: VAR 5 with every lo half zero (timing bound, wrong results) / with 8-bit lo halves
-    static const int var_of[] = {1, 2, 3, 8, 11, 4, 5, 21, 37};
+    // 14: the four-wave kernel (conv_lds_h3_w4)
+    static const int var_of[] = {1, 2, 3, 8, 11, 4, 5, 21, 37, 64};
     if (precision == 3) nn->variant = 0; // round 2's kernel: weights L2 -> registers per wave, residual decoded from LDS
-    if (precision >= 5 && precision <= 13) nn->variant = var_of[precision - 5];
+    if (precision >= 5 && precision <= 14) nn->variant = var_of[precision - 5];
 #endif
     return nn;
 }
@@ -2015,6 +2202,13 @@ static hipError_t tower_dispatch_c2(NNState *nn, hipStream_t s, const TowerArgs 
     case 4: return tower_dispatch_c2v<4>(nn, s, ta, nt, grid, attr_only);
     case 21: return tower_dispatch_c2v<21>(nn, s, ta, nt, grid, attr_only);
     case 37: return tower_dispatch_c2v<37>(nn, s, ta, nt, grid, attr_only);
+    case 64: // MF = 3: four waves, four cout tiles x four position tiles each (NT = 4 geometries; others stay on the 8-wave kernel)
+        if (nt == 4) {
+            if (attr_only) return hipFuncSetAttribute((const void *)k_tower<64, 4, 0, 1, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nn->conv_lds_c2);
+            hipLaunchKernelGGL((k_tower<64, 4, 0, 1, 3, 5>), dim3(grid), dim3(256), nn->conv_lds_c2, s, nn->g, ta);
+            return hipSuccess;
+        }
+        break;
     default: break;
     }
 #endif
@@ -2428,7 +2622,7 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         int Sc = MAXROWS / HW;
         if (Sc > 16) Sc = 16;
         // (the shipped variant keeps a two-slot weight ring of 16 KB behind the images; 1.1 KB of static LDS besides)
-        const size_t ring = (nn->variant & 4) ? (size_t)2 * 512 * 16 : 0, budget_c2 = (size_t)160 * 1024 - 1536;
+        const size_t ring = (nn->variant & (4 | 64)) ? (size_t)2 * 512 * 16 : 0, budget_c2 = (size_t)160 * 1024 - 1536;
         while (Sc > 1 && lds_bytes(Sc) + ring > budget_c2) Sc--;
         nn->S_c2 = Sc;
         nn->NT_c2 = ((Sc * HW + 15) / 16 + 3) / 4;           // tiles per wave (4 groups)
