@@ -1039,7 +1039,13 @@ struct TowerArgs {
     float hosc;
     const float *w0p;        // f16x3: packed (hi, lo) fragments of w0 over k = tap*3 + c, padded to 32 (nullptr: VALU conv0)
     float osc0;
-    float *hact;             // out: [sample][2*hc*HW]
+    float *hact;             // out: [sample][2*hc*HW] (unused since the head FCs run inside the tower, kept for diagnostics)
+    // head FCs + softmax / tanh inside the tower workgroup (head_fc_fused)
+    const float *wfc, *bfc;  // packed FC weights [ntp+ntv][KP/16][64][4], bias [(ntp+ntv)*16]
+    const float *wv1, *bv1;  // value FC1 [vf], [1]
+    float *P, *V;            // out: softmax policy [slot][AS], tanh value [slot]
+    int KP, ntp, ntv, vf, AS;
+    int32_t *n_used;         // (optional) the count the step's network took (k_expand_backup: list positions >= n ask again next step)
     int *overflow;           // [0] sticky "an activation left f16's range", [1] samples re-evaluated in f32
     int *ovf_flags;          // per sample: its f16x3 workgroup overflowed (set by PREC 1, consumed by the fallback launch)
     int fallback;            // PREC 0 launch behind a PREC 1 one: only workgroups holding a flagged sample run
@@ -1049,6 +1055,67 @@ struct TowerArgs {
     int cut_round, cut_defer; // cut_n's rule for this step's list (0: every leaf)
     unsigned long long *stamp_out; // diagnostic build only
 };
+
+// ------------------------------------------------------------------------------------
+// Head FCs + softmax / tanh for the S samples of a tower workgroup, straight from the head activations it has just staged in LDS
+// (stage[sample][2 hc][HW], the reference's x.view(n, -1) flatten order: policy rows first, value rows behind them).
+// Policy FC (A outputs) and value FC0 (vf outputs) are ONE GEMM  Out^T[out][sample] = Wfc . hact^T  on v_mfma_f32_16x16x4_f32:
+// wave w owns the 16-output tiles w, w + #waves, ...; the samples are the MFMA's 16 columns (S <= 16); K runs in order, so a
+// sample's logits do not depend on the batch or the workgroup size it is evaluated in.  Weight fragments come from L2 in operand
+// layout, eight K-chunks per round trip.  (Until round 3 this was a kernel of its own, k_head_fc: 33 us per 6x6 step, 14.5 us per
+// 3x3 step, plus a kernel boundary and the round trip of the head activations through HBM; SimpleNN still uses it.)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void head_fc_fused(const Geo &g, const TowerArgs &a, const float *stage, float *lg, int ns, int s0,
+                                              int tid, int nthr)
+{
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    const int K = a.hc * g.HW, KC = a.KP / 16, NJ = a.ntp + a.ntv, LGS = NJ * 16 + 1, A = g.A;
+    const int jrow = lane & 15, gq = lane >> 4;
+    const f32x4 *wfc4 = reinterpret_cast<const f32x4 *>(a.wfc);
+    const float *rowp = stage + (size_t)min(jrow, ns - 1) * (2 * K) + gq * 4;
+    constexpr int G = 8; // K-chunks per weight round trip
+    for (int job = wave; job < NJ; job += nw) {
+        const float *brow = rowp + (job < a.ntp ? 0 : K);
+        const f32x4 *wp = wfc4 + (size_t)job * KC * 64 + lane;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 wc[G], wn[G];
+#pragma unroll
+        for (int j = 0; j < G; j++) wc[j] = j < KC ? wp[(size_t)j * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int base = 0; base < KC; base += G) {
+#pragma unroll
+            for (int j = 0; j < G; j++) wn[j] = base + G + j < KC ? wp[(size_t)(base + G + j) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < G; j++)
+                if (base + j < KC) {
+                    const f32x4 b = *reinterpret_cast<const f32x4 *>(brow + (base + j) * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j][e], b[e], acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < G; j++) wc[j] = wn[j];
+        }
+        if (jrow < ns) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) lg[jrow * LGS + job * 16 + gq * 4 + e] = acc[e] + a.bfc[job * 16 + gq * 4 + e];
+        }
+    }
+    __syncthreads();
+    for (int sidx = wave; sidx < ns; sidx += nw) {
+        const int dst = a.list ? a.list[s0 + sidx] : s0 + sidx;
+        const float *l = lg + sidx * LGS;
+        float mx = -INFINITY;
+        for (int o = lane; o < A; o += 64) mx = fmaxf(mx, l[o]);
+        for (int sh = 32; sh > 0; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
+        float sum = 0.0f;
+        for (int o = lane; o < A; o += 64) sum += expf(l[o] - mx);
+        for (int sh = 32; sh > 0; sh >>= 1) sum += __shfl_xor(sum, sh);
+        for (int o = lane; o < A; o += 64) a.P[(size_t)dst * a.AS + o] = expf(l[o] - mx) / sum;
+        float hv = 0.0f;
+        for (int u = lane; u < a.vf; u += 64) hv += fmaxf(l[a.ntp * 16 + u], 0.0f) * a.wv1[u];
+        for (int sh = 32; sh > 0; sh >>= 1) hv += __shfl_xor(hv, sh);
+        if (lane == 0) a.V[dst] = tanhf(hv + a.bv1[0]);
+    }
+}
 
 // the S samples [s0, s0 + ns) of one workgroup through the whole trunk
 template <int C, int NTA, int NTB, int PREC, int MF, int VAR = 0>
@@ -1440,9 +1507,11 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
                         if (oc0 + r < OC) stage[(sidx * OC + oc0 + r) * HW + pp] = fmaxf(v[r], 0.0f);
                 }
             }
+            // K may not be a multiple of the GEMM's 16-wide chunks (head_channels * HW): the last chunk reads up to 15 floats
+            // behind the last sample's rows -- their weights are zero, the values only have to be finite
+            if (tid < 16) stage[(size_t)ns * OC * HW + tid] = 0.0f;
             __syncthreads();
-            float *o = a.hact + (size_t)s0 * OC * HW;
-            for (int i = tid; i < ns * OC * HW; i += NTHR) o[i] = stage[i];
+            head_fc_fused(g, a, stage, stage + (size_t)S * OC * HW + 16, ns, s0, tid, NTHR);
             heads_done = true;
         }
     }
@@ -1474,9 +1543,9 @@ __device__ __forceinline__ void tower_group(const Geo &g, const TowerArgs &a, fl
                 stage[(sidx * OC + oc) * HW + p] = fmaxf(acc, 0.0f);
             }
         }
+        if (tid < 16) stage[(size_t)ns * OC * HW + tid] = 0.0f;
         __syncthreads();
-        float *o = a.hact + (size_t)s0 * OC * HW;
-        for (int i = tid; i < ns * OC * HW; i += NTHR) o[i] = stage[i];
+        head_fc_fused(g, a, stage, stage + (size_t)S * OC * HW + 16, ns, s0, tid, NTHR);
     }
     if (PREC == 1 && ovf) {
         // (every thread that saw it says so; the stores are idempotent)
@@ -1565,6 +1634,7 @@ __global__ void __launch_bounds__(MF == 3 ? 256 : CONV_THREADS, 1) k_tower(Geo g
             return;
         }
     }
+    if (a.n_used && a.role == 0 && !a.fallback && blockIdx.x == 0 && threadIdx.x == 0) *a.n_used = n;
     const int s0 = first_sample + blockIdx.x * S;
     if (s0 >= limit) return;
     tower_group<C, NTA, NTB, PREC, MF, VAR>(g, a, lds, S, s0, min(S, limit - s0));
@@ -2566,7 +2636,9 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
         const size_t s4 = (C + 8) / 4;
         const size_t img = ((((size_t)S_ * HW * s4 + 15) & ~(size_t)15) + 3 * s4) * 4; // floats, incl. zero region
         const size_t need0 = (size_t)S_ * 3 * (g.H + 2) * (g.W + 2) + (size_t)27 * C;
-        const size_t need1 = (size_t)2 * hc * (C + 4) + (size_t)S_ * 2 * hc * HW;
+        // head phase: conv1x1 weights (VALU path) + staged head activations + 16 floats of slack + the FC logits of the samples
+        const size_t nj = (size_t)(A + 15) / 16 + (size_t)(vf + 15) / 16;
+        const size_t need1 = (size_t)2 * hc * (C + 4) + (size_t)S_ * 2 * hc * HW + 16 + (size_t)S_ * (nj * 16 + 1);
         return (img + std::max(img, std::max(need0, need1))) * 4;
     };
     int S = (16 * MAXT) / HW;
@@ -2600,7 +2672,8 @@ int nn_commit(NNState *nn, hipStream_t s, std::string &err)
             const size_t s4 = (C + 4) / 4;
             const size_t img = ((((size_t)S_ * HW * s4 + 15) & ~(size_t)15) + 3 * s4) * 4;
             const size_t need0 = (size_t)S_ * 3 * (g.H + 2) * (g.W + 2) + (size_t)27 * C;
-            const size_t need1 = (size_t)2 * hc * (C + 4) + (size_t)S_ * 2 * hc * HW;
+            const size_t nj = (size_t)(A + 15) / 16 + (size_t)(vf + 15) / 16;
+            const size_t need1 = (size_t)2 * hc * (C + 4) + (size_t)S_ * 2 * hc * HW + 16 + (size_t)S_ * (nj * 16 + 1);
             return (img + std::max(img, std::max(need0, need1))) * 4;
         };
         int Sm = MAXROWS / HW;
@@ -2691,6 +2764,8 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
     ta.feat = feat; ta.list = list_dev; ta.n_dev = n_dev; ta.in_s = nn->in_s; ta.in_t = nn->in_t; ta.w0 = nn->w0; ta.b0 = nn->b0;
     ta.tw = nn->tw; ta.tb = nn->tb; ta.tosc = nn->tosc; ta.hw = nn->hw; ta.hb = nn->hb; ta.hwp = nn->hwp; ta.hosc = nn->hosc; ta.w0p = nn->w0p; ta.osc0 = nn->osc0; ta.hact = nn->hact;
     ta.overflow = nn->overflow; ta.ovf_flags = nn->ovf_flags; ta.fallback = 0; ta.S = nn->S; ta.nblocks = nn->blocks; ta.hc = hc;
+    ta.wfc = nn->wfc; ta.bfc = nn->bfc; ta.wv1 = nn->wv1; ta.bv1 = nn->bv1; ta.P = P; ta.V = V; ta.KP = nn->KP; ta.ntp = nn->ntp;
+    ta.ntv = nn->ntv; ta.vf = nn->vf; ta.AS = AS; ta.n_used = n_used;
     ta.stamp_out = nn->stamp_out;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     ta.S_main = nn->S; ta.S_small = nn->S_small; ta.S_mid = nn->S_mid; ta.S_big = nn->S_big; ta.S_huge = 0; ta.cus = nn->cus;
@@ -2739,11 +2814,8 @@ void nn_forward(NNState *nn, hipStream_t s, const float *feat, const int32_t *li
         (void)tower_dispatch(nn, s, ta, nn->NTT, std::min((max_n + nn->S - 1) / nn->S, nn->cus), false, 0);
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    HeadArgs ha;
-    ha.list = list_dev; ha.n_dev = n_dev; ha.hact = nn->hact; ha.wfc = nn->wfc; ha.bfc = nn->bfc; ha.wv1 = nn->wv1; ha.bv1 = nn->bv1;
-    ha.P = P; ha.V = V; ha.K = hc * HW; ha.KP = nn->KP; ha.RS4 = nn->RS4; ha.ntp = nn->ntp; ha.ntv = nn->ntv; ha.vf = nn->vf; ha.AS = AS;
-    ha.value_direct = 0; ha.cut_round = cut_round; ha.cut_defer = cut_defer; ha.n_used = n_used;
-    hipLaunchKernelGGL(k_head_fc, dim3((max_n + 16 * HEAD_MT - 1) / (16 * HEAD_MT)), dim3(256), nn->fc_lds, s, g, ha);
+    // (the head FCs, softmax and tanh ran inside the tower workgroups: head_fc_fused)
+    (void)HW;
 }
 
 void nn_round_info(const NNState *nn, int *round, int *rem_max)
