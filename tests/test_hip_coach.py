@@ -113,43 +113,60 @@ def test_generation_loop_trains_through_the_hip_tower(tmp_path):
 
 
 def test_validation_on_the_hip_engine_equals_torchs_eval_forward(tmp_path):
-    """NeuralNetWrapper.train runs its validation passes (nn.py:223-246) on the HIP inference engine by default: the logged
-    validation losses and accuracy must equal those of torch's eval-mode forward of the same weights (hip_validation=False)
-    within 1e-4, and the training itself (scalars, weights) must not depend on the choice."""
+    """NeuralNetWrapper.train runs its validation passes (nn.py:223-246) on the HIP inference engine by default.  For a network
+    that has been trained for a generation, the per-batch validation losses (AlphaZeroLoss on log p, v) and the value accuracy
+    count computed from the engine's (p, v) must equal those of torch's eval-mode forward of the same weights within 1e-4 --
+    log(softmax) against log_softmax included -- and hip_validation=False must select torch's forward."""
     import torch
     from dotsboxesaz_amd import nn as dnn
     from dotsboxesaz_amd import train as T
+    from dotsboxesaz_amd import train_data as TD
     from dotsboxesaz_amd.coach import Coach
-    runs = {}
-    for hipval in (True, False):
-        params = dnn.resnet_params(3, 3, 32, 2, 4, 8)
-        params["nn"]["model_class"] = dnn.ResNetZero
-        params["nn"]["chkpts_filename"] = str(tmp_path / ("m%d_gen{}.pt" % hipval))
-        params["nn"]["train_params"] = {"nb_epochs": 2, "train_batch_size": 128, "val_batch_size": 32, "lr": 1e-2,
-                                        "lr_scheduler": T.GenerationLrScheduler({0: 1e-2}), "optimizer_params": {"momentum": 0.9, "weight_decay": 1e-4},
-                                        "pos_average": False, "train_split": 0.8, "max_samples_per_gen": 100000, "symmetries": None}
-        params["self_play"] = {"num_games": 64, "reuse_mcts_tree": True, "noise": (0.8, 0.25),
-                               "mcts": {"mcts_num_read": 16, "mcts_cpuct": (1.25, 19652), "temperature": {0: 1.0, 6: 0.02}}}
-        torch.manual_seed(0)
-        np.random.seed(0)
-        import random
-        random.seed(0)
-        coach = Coach(params, 3, 3, n_slots=32)
-        w = Writer()
-        for g in (0, 1):
-            coach.selfplay(g)
-            model = coach.model_class(params)
-            wrapper = dnn.NeuralNetWrapper(model, params, engine=coach.engine)
-            from dotsboxesaz_amd import train_data as TD
-            params["nn"]["train_params"]["symmetries"] = TD.SymmetriesGenerator(coach.engine)
-            tr = coach.store.dataset(train=True, min_generation=0, pos_average=False)
-            va = coach.store.dataset(train=False, min_generation=0, pos_average=False)
-            wrapper.train(tr, va, w, g, hip_validation=hipval)
-        runs[hipval] = {t: [v for tt, v, _ in w.s if tt == t] for t in ("loss/pi/eval", "loss/v/eval", "accuracy/v/eval", "loss/total/train")}
-        coach.close()
-    a, b = runs[True], runs[False]
-    assert len(a["loss/pi/eval"]) == len(b["loss/pi/eval"]) >= 2
-    assert np.allclose(a["loss/total/train"], b["loss/total/train"], rtol=0, atol=1e-6)   # training is untouched by the choice
-    for k in ("loss/pi/eval", "loss/v/eval"):
-        assert np.max(np.abs(np.array(a[k]) - np.array(b[k]))) < 1e-4, (k, a[k], b[k])
-    assert np.max(np.abs(np.array(a["accuracy/v/eval"]) - np.array(b["accuracy/v/eval"]))) < 0.02
+    params = dnn.resnet_params(3, 3, 32, 2, 4, 8)
+    params["nn"]["model_class"] = dnn.ResNetZero
+    params["nn"]["chkpts_filename"] = str(tmp_path / "m_gen{}.pt")
+    params["nn"]["train_params"] = {"nb_epochs": 2, "train_batch_size": 128, "val_batch_size": 32, "lr": 1e-2,
+                                    "lr_scheduler": T.GenerationLrScheduler({0: 1e-2}), "optimizer_params": {"momentum": 0.9, "weight_decay": 1e-4},
+                                    "pos_average": False, "train_split": 0.8, "max_samples_per_gen": 100000, "symmetries": None}
+    params["self_play"] = {"num_games": 64, "reuse_mcts_tree": True, "noise": (0.8, 0.25),
+                           "mcts": {"mcts_num_read": 16, "mcts_cpuct": (1.25, 19652), "temperature": {0: 1.0, 6: 0.02}}}
+    params["elo"] = None
+    torch.manual_seed(0)
+    np.random.seed(0)
+    coach = Coach(params, 3, 3, n_slots=32)
+    w = Writer()
+    coach.learn_to_play(0, 1, writer=w)                      # generation 1 trains two epochs, validating on the engine
+    assert len([v for t, v, _ in w.s if t == "loss/total/eval"]) == 2
+    ck = torch.load(params["nn"]["chkpts_filename"].format(1), map_location="cpu", weights_only=True)
+    model = dnn.ResNetZero(params)
+    model.load_state_dict(ck["model_dict"])
+    model.train(False).cuda()
+    coach.engine.load_state_dict(model.state_dict(), "resnet", **model.shape)
+    val = coach.store.dataset(train=False, min_generation=0, pos_average=False)
+    crit = T.AlphaZeroLoss()
+    n = 0
+    for boards, pi, z in T._batches(val, 32, False, None, torch.device("cuda", 0)):
+        with torch.no_grad():
+            lp_t, v_t = T.training_forward(model, boards)
+        p, v = coach.engine.predict(boards.cpu().numpy())
+        lp_h = torch.log(torch.from_numpy(p).clamp_min(1e-38)).cuda()
+        v_h = torch.from_numpy(v).cuda()
+        _, (lpi_t, lv_t) = crit(lp_t, v_t, pi, z)
+        _, (lpi_h, lv_h) = crit(lp_h, v_h, pi, z)
+        assert abs(lpi_t - lpi_h) < 1e-4 and abs(lv_t - lv_h) < 1e-4, (lpi_t, lpi_h, lv_t, lv_h)
+        assert T._accuracy(v_t, z)[0] == T._accuracy(v_h, z)[0]
+        n += 1
+    assert n >= 2
+    # the switch: hip_validation=False must not touch the engine's predict
+    wrapper = dnn.NeuralNetWrapper(dnn.ResNetZero(params), params, engine=coach.engine)
+    calls = []
+    real = coach.engine.predict
+    coach.engine.predict = lambda X: calls.append(1) or real(X)
+    tr = coach.store.dataset(train=True, min_generation=0, pos_average=False)
+    params["nn"]["train_params"]["symmetries"] = TD.SymmetriesGenerator(coach.engine)
+    wrapper.train(tr, val, Writer(), 1, hip_validation=False)
+    assert not calls
+    wrapper.train(tr, val, Writer(), 1, hip_validation=True)
+    assert calls
+    coach.engine.predict = real
+    coach.close()
