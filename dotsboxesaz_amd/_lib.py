@@ -25,10 +25,11 @@ SYMBOLS = [
     "dbaz_get_roots", "dbaz_get_root_states", "dbaz_advance",
     "dbaz_selfplay_start", "dbaz_selfplay_script", "dbaz_selfplay_fastforward", "dbaz_selfplay_stagger", "dbaz_selfplay_quickplay", "dbaz_step", "dbaz_run",
     "dbaz_get_counters", "dbaz_timing_begin", "dbaz_timing_end", "dbaz_fetch_samples", "dbaz_replay_rows_dev",
-    "dbaz_replay_rows_clear", "dbaz_dataset_select", "dbaz_dataset_begin", "dbaz_dataset_add_rows", "dbaz_dataset_finish", "dbaz_dataset_fetch", "dbaz_dataset_batch",
+    "dbaz_replay_rows_clear", "dbaz_dataset_select", "dbaz_dataset_begin", "dbaz_dataset_add_rows", "dbaz_dataset_finish", "dbaz_dataset_fetch", "dbaz_dataset_batch", "dbaz_dataset_batch_on",
     "dbaz_symmetry_apply", "dbaz_symmetry_table",
     "dbaz_trainer_last_error", "dbaz_trainer_create", "dbaz_trainer_destroy", "dbaz_trainer_forward", "dbaz_trainer_backward",
     "dbaz_bn2d_workspace_bytes", "dbaz_bn2d_forward", "dbaz_bn2d_backward",
+    "dbaz_az_loss_workspace_bytes", "dbaz_az_loss", "dbaz_sgd_step",
 ]
 
 
@@ -138,11 +139,16 @@ def load():
     L.dbaz_bn2d_workspace_bytes.argtypes = [i32]
     L.dbaz_bn2d_forward.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp]
     L.dbaz_bn2d_backward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.dbaz_az_loss_workspace_bytes.argtypes = []
+    L.dbaz_az_loss.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp]
+    L.dbaz_sgd_step.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i32, C.c_float, C.c_float, C.c_float, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("dbaz_last_error", "dbaz_build_info", "dbaz_destroy", "dbaz_trainer_last_error", "dbaz_trainer_destroy", "dbaz_bn2d_workspace_bytes"):
+        if name not in ("dbaz_last_error", "dbaz_build_info", "dbaz_destroy", "dbaz_trainer_last_error", "dbaz_trainer_destroy", "dbaz_bn2d_workspace_bytes",
+                        "dbaz_az_loss_workspace_bytes"):
             fn.restype = C.c_int
     L.dbaz_bn2d_workspace_bytes.restype = C.c_int64
+    L.dbaz_az_loss_workspace_bytes.restype = C.c_int64
     _lib = L
     return L
 

@@ -1334,6 +1334,12 @@ extern "C" int dbaz_dataset_batch(dbaz_engine *e, const int32_t *idx, int32_t n,
     RDS(e);
     RDS_RET(e, rds_batch(e->rds, e->stream, idx, n, sym, boards_dev, pi_dev, z_dev, _err));
 }
+extern "C" int dbaz_dataset_batch_on(dbaz_engine *e, const int32_t *idx, int32_t n, int32_t sym, float *boards_dev, float *pi_dev,
+                                     float *z_dev, void *stream)
+{
+    RDS(e);
+    RDS_RET(e, rds_batch(e->rds, (hipStream_t)stream, idx, n, sym, boards_dev, pi_dev, z_dev, _err, true));
+}
 extern "C" int dbaz_symmetry_apply(dbaz_engine *e, int32_t sym, const float *boards_in_dev, const float *pol_in_dev, int64_t n,
                                    float *boards_out_dev, float *pol_out_dev)
 {

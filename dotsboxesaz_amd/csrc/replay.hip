@@ -69,6 +69,14 @@ struct ReplayDS {
     DevBuf lut;                              // [8][A] symmetry source indices
     DevBuf idx;                              // batch indices
     bool lut_ready = false;
+    // batches queued on the caller's stream: a ring of pinned index buffers (host -> device copies from pinned memory are
+    // asynchronous; a slot is reused only after the copy that read it has completed) and of device index buffers
+    static constexpr int IDX_RING = 4;
+    int32_t *idx_pin[IDX_RING] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t *idx_dev[IDX_RING] = {nullptr, nullptr, nullptr, nullptr};
+    size_t idx_cap[IDX_RING] = {0, 0, 0, 0};
+    hipEvent_t idx_ev[IDX_RING] = {nullptr, nullptr, nullptr, nullptr};
+    int idx_slot = 0;
 };
 
 #define RCHECK(call)                                                                    \
@@ -368,6 +376,11 @@ void rds_destroy(ReplayDS *d)
     DevBuf *all[] = {&d->st_x, &d->st_vis, &d->st_z, &d->st_key, &d->perm, &d->perm2, &d->keyw, &d->keyw2, &d->flag, &d->gid,
                      &d->gstart, &d->tmp, &d->sel, &d->err, &d->ds_x, &d->ds_pi, &d->ds_z, &d->lut, &d->idx};
     for (DevBuf *b : all) b->release();
+    for (int i = 0; i < ReplayDS::IDX_RING; i++) {
+        if (d->idx_ev[i]) { (void)hipEventSynchronize(d->idx_ev[i]); (void)hipEventDestroy(d->idx_ev[i]); }
+        if (d->idx_pin[i]) (void)hipHostFree(d->idx_pin[i]);
+        if (d->idx_dev[i]) (void)hipFree(d->idx_dev[i]);
+    }
     delete d;
 }
 
@@ -527,8 +540,11 @@ int rds_fetch(ReplayDS *d, hipStream_t s, int16_t *x, float *pi, float *z, std::
     return DBAZ_OK;
 }
 
+// on_caller_stream: the batch is QUEUED on `s` (the caller's own stream, e.g. torch's current one) and the call returns at once:
+// the indices are checked on the host, nothing is read back.  Writing the caller's freshly allocated tensors from another stream
+// would race with work the caller has queued on the memory's previous owner (a caching allocator recycles blocks in stream order).
 int rds_batch(ReplayDS *d, hipStream_t s, const int32_t *idx_host, int n, int sym, float *boards_dev, float *pi_dev, float *z_dev,
-              std::string &err)
+              std::string &err, bool on_caller_stream)
 {
     if (!d->finished) { err = "no dataset: call dbaz_dataset_finish first"; return DBAZ_ESTATE; }
     if (sym < 0 || sym > 7) { err = "symmetry id must be 0..7"; return DBAZ_EINVAL; }
@@ -536,19 +552,46 @@ int rds_batch(ReplayDS *d, hipStream_t s, const int32_t *idx_host, int n, int sy
     if (n == 0) return DBAZ_OK;
     if (n < 0 || !idx_host || !boards_dev || !pi_dev || !z_dev) { err = "null argument"; return DBAZ_EINVAL; }
     const int F = 3 * d->g.HW, A = d->g.A;
+    if (on_caller_stream)
+        for (int i = 0; i < n; i++)
+            if (idx_host[i] < 0 || (long long)idx_host[i] >= (long long)d->n_out) { err = "batch index out of range"; return DBAZ_EINVAL; }
     int rc = ensure_lut(d, s, err);
     if (rc) return rc;
-    RCHECK(d->idx.ensure((size_t)n * 4, false, s));
     RCHECK(d->err.ensure(16, false, s));
-    RCHECK(hipMemsetAsync(d->err.p, 0, 16, s));
-    RCHECK(hipMemcpyAsync(d->idx.p, idx_host, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    const int32_t *idx_dev = nullptr;
+    if (on_caller_stream) {
+        const int k = d->idx_slot;
+        d->idx_slot = (k + 1) % ReplayDS::IDX_RING;
+        if (d->idx_ev[k]) RCHECK(hipEventSynchronize(d->idx_ev[k])); // (only if the device is IDX_RING batches behind)
+        else RCHECK(hipEventCreateWithFlags(&d->idx_ev[k], hipEventDisableTiming));
+        if (d->idx_cap[k] < (size_t)n) {
+            if (d->idx_pin[k]) RCHECK(hipHostFree(d->idx_pin[k]));
+            if (d->idx_dev[k]) RCHECK(hipFree(d->idx_dev[k]));
+            d->idx_pin[k] = nullptr; d->idx_dev[k] = nullptr; d->idx_cap[k] = 0;
+            RCHECK(hipHostMalloc((void **)&d->idx_pin[k], (size_t)n * 4, hipHostMallocDefault));
+            RCHECK(hipMalloc((void **)&d->idx_dev[k], (size_t)n * 4));
+            d->idx_cap[k] = (size_t)n;
+        }
+        memcpy(d->idx_pin[k], idx_host, (size_t)n * 4);
+        RCHECK(hipMemcpyAsync(d->idx_dev[k], d->idx_pin[k], (size_t)n * 4, hipMemcpyHostToDevice, s));
+        idx_dev = d->idx_dev[k];
+    } else {
+        RCHECK(d->idx.ensure((size_t)n * 4, false, s));
+        RCHECK(hipMemsetAsync(d->err.p, 0, 16, s));
+        RCHECK(hipMemcpyAsync(d->idx.p, idx_host, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        idx_dev = (const int32_t *)d->idx.p;
+    }
     const int32_t *lut = sym ? (const int32_t *)d->lut.p + (size_t)sym * A : nullptr;
     const size_t lds_batch = (size_t)A * 4 + 4 * ((size_t)d->FP * 2 + (size_t)A * 4);
     hipLaunchKernelGGL(k_make_batch, dim3(std::min((n + 3) / 4, 256 * 32)), dim3(256), lds_batch, s, (const int16_t *)d->ds_x.p,
-                       (const float *)d->ds_pi.p, (const float *)d->ds_z.p, (const int32_t *)d->idx.p, n, d->n_out, lut, F, d->FP, A,
+                       (const float *)d->ds_pi.p, (const float *)d->ds_z.p, idx_dev, n, d->n_out, lut, F, d->FP, A,
                        boards_dev, pi_dev, z_dev,
                        (int32_t *)d->err.p);
     RCHECK(hipGetLastError());
+    if (on_caller_stream) { // (indices were validated below the argument checks; ordering is the stream's)
+        RCHECK(hipEventRecord(d->idx_ev[d->idx_slot == 0 ? ReplayDS::IDX_RING - 1 : d->idx_slot - 1], s));
+        return DBAZ_OK;
+    }
     int flag = 0;
     rc = read_errflag(d, s, flag, err); // also orders the batch before the caller's own stream
     if (rc) return rc;

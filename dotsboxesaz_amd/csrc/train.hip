@@ -1294,3 +1294,134 @@ extern "C" int dbaz_bn2d_backward(const float *dout, const float *out, const flo
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DBAZ_OK : terr(nullptr, DBAZ_EDEVICE, "bn2d backward: %s", hipGetErrorString(e));
 }
+
+// ------------------------------------------------------------------------------------
+// AlphaZeroLoss (nn.py:131-138) forward + backward and torch.optim.SGD's update (nn.py:179, 203-221: momentum, weight
+// decay) as HIP kernels -- the parts of the optimizer step around the network that are pure elementwise / reduction work.
+// Stateless C calls on DEVICE pointers, asynchronous on `stream`; errors: dbaz_trainer_last_error(NULL).
+// ------------------------------------------------------------------------------------
+#define LOSS_NB 128 // partial-sum workgroups of the loss
+
+// loss_v = mean((z - v)^2), loss_pi = -mean_n(sum_a pi * logp); gradients of (loss_v + loss_pi) * gscale.
+// One wave per sample row; partial sums in f64 per workgroup, added in workgroup order by k_az_loss_fin (deterministic).
+__global__ void __launch_bounds__(256) k_az_loss(const float *__restrict__ logp, const float *__restrict__ v, const float *__restrict__ pi,
+                                                 const float *__restrict__ z, int n, int A, float gscale, float *__restrict__ d_logp,
+                                                 float *__restrict__ d_v, double *__restrict__ part)
+{
+    __shared__ double sh[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_n = 1.0f / (float)n;
+    double s_pi = 0.0, s_v = 0.0;
+    for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+        const float *lp = logp + (size_t)row * A, *pr = pi + (size_t)row * A;
+        float acc = 0.0f;
+        for (int a = lane; a < A; a += 64) {
+            const float p = pr[a];
+            acc += p * lp[a];
+            if (d_logp) d_logp[(size_t)row * A + a] = -p * inv_n * gscale;
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) {
+            const float d = v[row] - z[row];
+            s_pi += (double)acc;
+            s_v += (double)(d * d);
+            if (d_v) d_v[row] = 2.0f * d * inv_n * gscale;
+        }
+    }
+    if (lane == 0) { sh[wave][0] = s_pi; sh[wave][1] = s_v; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+        part[blockIdx.x * 2 + 1] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_az_loss_fin(const double *__restrict__ part, int nb, int n, float *__restrict__ loss3)
+{
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) { a += part[i * 2]; b += part[i * 2 + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (threadIdx.x == 0) {
+        const float lpi = (float)(-a / (double)n), lv = (float)(b / (double)n);
+        loss3[0] = lv + lpi; // AlphaZeroLoss.forward: loss_v + loss_pi
+        loss3[1] = lpi;
+        loss3[2] = lv;
+    }
+}
+
+extern "C" int64_t dbaz_az_loss_workspace_bytes(void) { return (int64_t)LOSS_NB * 2 * 8; }
+
+extern "C" int dbaz_az_loss(const float *logp, const float *v, const float *pi, const float *z, int32_t n, int32_t n_actions, float grad_scale,
+                            float *loss3, float *d_logp, float *d_v, void *workspace, void *stream)
+{
+    if (!logp || !v || !pi || !z || !loss3 || !workspace || n < 1 || n_actions < 1) return terr(nullptr, DBAZ_EINVAL, "dbaz_az_loss: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = std::min(LOSS_NB, (n + 3) / 4);
+    hipLaunchKernelGGL(k_az_loss, dim3(nb), dim3(256), 0, s, logp, v, pi, z, n, n_actions, grad_scale, d_logp, d_v, (double *)workspace);
+    hipLaunchKernelGGL(k_az_loss_fin, dim3(1), dim3(64), 0, s, (const double *)workspace, nb, n, loss3);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DBAZ_OK : terr(nullptr, DBAZ_EDEVICE, "az loss: %s", hipGetErrorString(e));
+}
+
+// torch.optim.SGD (dampening 0, no nesterov): d = g + wd p; buf = momentum buf + d; p -= lr buf -- every parameter tensor of the
+// model in ONE launch.  table[t] = {p, g, buf, numel}; chunk c of SGD_CHUNK elements belongs to tensor chunk_tensor[c] at
+// element offset chunk_off[c].  The operation order (and its roundings) is torch's _foreach implementation's:
+// g + wd*p as one fma, buf*momentum then + d, p + (-lr)*buf as one fma.
+#define SGD_CHUNK 2048
+struct SgdEntry { float *p; const float *g; float *buf; long long numel; };
+
+__global__ void __launch_bounds__(256) k_sgd(const SgdEntry *__restrict__ table, const int32_t *__restrict__ chunk_tensor,
+                                             const int32_t *__restrict__ chunk_off, float lr, float momentum, float wd)
+{
+    const SgdEntry e = table[chunk_tensor[blockIdx.x]];
+    const long long base = (long long)chunk_off[blockIdx.x] * SGD_CHUNK;
+    for (int k = 0; k < SGD_CHUNK / 256; k++) {
+        const long long i = base + k * 256 + threadIdx.x;
+        if (i < e.numel) {
+            float p = e.p[i];
+            float d = wd != 0.0f ? fmaf(wd, p, e.g[i]) : e.g[i];
+            if (momentum != 0.0f) {
+                float b = e.buf[i] * momentum;
+                b = b + d;
+                e.buf[i] = b;
+                d = b;
+            }
+            e.p[i] = fmaf(-lr, d, p);
+        }
+    }
+}
+
+// the pointer table travels to the device as KERNEL ARGUMENTS (96 entries per launch): the gradient tensors are new ones every
+// step, and a host -> device copy of 10 KB on the compute stream makes the host wait for the device to get there (measured:
+// +2 ms per training step, the host loses its run-ahead); kernel arguments are copied by the launch itself
+#define SGD_ARGS 96
+struct SgdArgs { SgdEntry e[SGD_ARGS]; };
+__global__ void __launch_bounds__(128) k_sgd_table(SgdArgs a, int n, SgdEntry *__restrict__ table)
+{
+    if ((int)threadIdx.x < n) table[threadIdx.x] = a.e[threadIdx.x];
+}
+
+extern "C" int dbaz_sgd_step(int32_t n_tensors, const void *const *params, const void *const *grads, const void *const *bufs,
+                             const int64_t *numels, void *table_dev, const int32_t *chunk_tensor_dev, const int32_t *chunk_off_dev,
+                             int32_t n_chunks, float lr, float momentum, float weight_decay, void *stream)
+{
+    if (n_tensors < 0 || !params || !grads || !numels || !table_dev || !chunk_tensor_dev || !chunk_off_dev || n_chunks < 0)
+        return terr(nullptr, DBAZ_EINVAL, "dbaz_sgd_step: bad argument");
+    if (n_chunks == 0 || n_tensors == 0) return DBAZ_OK;
+    SgdEntry *table = (SgdEntry *)table_dev;
+    for (int base = 0; base < n_tensors; base += SGD_ARGS) {
+        SgdArgs a;
+        const int n = std::min(SGD_ARGS, n_tensors - base);
+        for (int i = 0; i < n; i++) {
+            a.e[i].p = (float *)params[base + i];
+            a.e[i].g = (const float *)grads[base + i];
+            a.e[i].buf = bufs ? (float *)bufs[base + i] : nullptr;
+            a.e[i].numel = numels[base + i];
+        }
+        hipLaunchKernelGGL(k_sgd_table, dim3(1), dim3(128), 0, (hipStream_t)stream, a, n, table + base);
+    }
+    hipLaunchKernelGGL(k_sgd, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const SgdEntry *)table_dev, chunk_tensor_dev, chunk_off_dev, lr,
+                       momentum, weight_decay);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DBAZ_OK : terr(nullptr, DBAZ_EDEVICE, "sgd step: %s", hipGetErrorString(e));
+}

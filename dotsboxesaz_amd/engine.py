@@ -403,7 +403,8 @@ class Engine:
 
     def dataset_batch(self, idx, sym=0):
         """Rows idx of the dataset under symmetry sym as torch CUDA tensors
-        (boards float32 [n,3,H,W], pi [n,A], z [n,1]) -- written by the HIP kernel, no host copy."""
+        (boards float32 [n,3,H,W], pi [n,A], z [n,1]) -- written by the HIP kernel, no host copy; asynchronous, ordered on torch's
+        current stream like any torch op."""
         import torch
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         n = len(idx)
@@ -411,8 +412,12 @@ class Engine:
         boards = torch.empty((n, 3, self.H, self.W), dtype=torch.float32, device=dev)
         pi = torch.empty((n, self.A), dtype=torch.float32, device=dev)
         z = torch.empty((n, 1), dtype=torch.float32, device=dev)
-        self._ck(self._L.dbaz_dataset_batch(self.h, C.c_void_p(_p(idx)), C.c_int32(n), C.c_int32(sym),
-                                            C.c_void_p(boards.data_ptr()), C.c_void_p(pi.data_ptr()), C.c_void_p(z.data_ptr())))
+        # queued on torch's CURRENT stream: the tensors above come from torch's stream-ordered caching allocator, so a kernel on any
+        # other stream could overwrite a recycled block while work queued on its previous owner is still pending
+        with torch.cuda.device(dev):
+            self._ck(self._L.dbaz_dataset_batch_on(self.h, C.c_void_p(_p(idx)), C.c_int32(n), C.c_int32(sym), C.c_void_p(boards.data_ptr()),
+                                                   C.c_void_p(pi.data_ptr()), C.c_void_p(z.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return boards, pi, z
 
     def symmetry_apply(self, sym, boards=None, policies=None):

@@ -66,20 +66,143 @@ def training_forward(model, x, hip_tower=None):
     return p, v
 
 
+class _AzLossFn(torch.autograd.Function):
+    """AlphaZeroLoss forward + backward in two HIP launches (dbaz_az_loss, csrc/train.hip): returns the 3-vector
+    (loss_v + loss_pi, loss_pi, loss_v); gradients flow to the policy log-probabilities and the value."""
+
+    @staticmethod
+    def forward(ctx, p, v, pi, z):
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        pc, vc = p.detach().contiguous().float(), v.detach().contiguous().float()
+        pic, zc = pi.detach().contiguous().float(), z.detach().contiguous().float()
+        n, A = pc.shape
+        loss3 = torch.empty(3, dtype=torch.float32, device=pc.device)
+        d_p, d_v = torch.empty_like(pc), torch.empty_like(vc)
+        ws = torch.empty(int(L.dbaz_az_loss_workspace_bytes()) // 8, dtype=torch.float64, device=pc.device)
+        with torch.cuda.device(pc.device):
+            rc = L.dbaz_az_loss(pc.data_ptr(), vc.data_ptr(), pic.data_ptr(), zc.data_ptr(), n, A, 1.0, loss3.data_ptr(), d_p.data_ptr(),
+                                d_v.data_ptr(), ws.data_ptr(), C.c_void_p(torch.cuda.current_stream(pc.device).cuda_stream))
+        if rc != _lib.OK:
+            raise RuntimeError((L.dbaz_trainer_last_error(None) or b"dbaz_az_loss failed").decode())
+        ctx.save_for_backward(d_p, d_v)
+        ctx.v_shape = v.shape
+        return loss3
+
+    @staticmethod
+    def backward(ctx, g3):
+        d_p, d_v = ctx.saved_tensors
+        g = g3[0]  # only the total carries a gradient (loss_pi / loss_v are read out detached)
+        return d_p * g, (d_v * g).view(ctx.v_shape), None, None
+
+
 class AlphaZeroLoss(tnn.Module):
     """nn.py:131-138: mean squared value error + mean cross entropy against the MCTS policy;
-    returns (loss, (loss_pi, loss_v) as python floats)."""
+    returns (loss, (loss_pi, loss_v) as python floats).  On CUDA float32 tensors the forward and backward run as HIP kernels
+    (dbaz_az_loss); elsewhere (the CPU goldens of tests/golden/train.npz) in torch, statement for statement as the reference."""
 
     def forward(self, p, v, pi, z):
         loss, (loss_pi, loss_v) = self.tensors(p, v, pi, z)
         return loss, (loss_pi.item(), loss_v.item())
 
     @staticmethod
-    def tensors(p, v, pi, z):
-        """The same without the two host synchronisations of `.item()`: (loss, (loss_pi, loss_v)) as 0-d tensors."""
+    def tensors(p, v, pi, z, hip=None):
+        """The same without the two host synchronisations of `.item()`: (loss, (loss_pi, loss_v)) as 0-d tensors.
+        hip: None = the HIP kernels whenever the tensors are CUDA float32 [n, A] / [n, 1]; False = torch."""
+        use = hip is not False and p.is_cuda and p.dtype == torch.float32 and p.dim() == 2 and v.numel() == p.shape[0] \
+            and z.numel() == p.shape[0] and pi.shape == p.shape
+        if hip is True and not use:
+            raise RuntimeError("the HIP loss needs CUDA float32 tensors p, pi [n, A] and v, z [n, 1]")
+        if use:
+            l3 = _AzLossFn.apply(p, v, pi, z)
+            return l3[0], (l3[1].detach(), l3[2].detach())
         loss_v = (z - v).pow(2).mean()
         loss_pi = -(pi * p).sum(1).mean()
         return loss_v + loss_pi, (loss_pi.detach(), loss_v.detach())
+
+
+class HipSGD(torch.optim.SGD):
+    """torch.optim.SGD (momentum, weight decay; dampening 0, no nesterov: what the reference configures, nn.py:179 with
+    configuration.py:62-66) whose step() is ONE HIP launch over all parameter tensors (dbaz_sgd_step, csrc/train.hip) instead of
+    torch's three or four multi-tensor launches (the tensors' pointers travel as kernel arguments).  It IS a torch SGD: param_groups, state[p]["momentum_buffer"], state_dict() and
+    load_state_dict() are torch's, so the reference's checkpoints ({'optimizer_dict': optimizer.state_dict()}, nn.py:292-313)
+    load and save unchanged.  Anything the kernel does not cover (CPU parameters, nesterov, dampening, maximize, sparse or
+    non-float32 gradients) goes through torch's own step()."""
+
+    def _plan(self, params):
+        """Chunk tables, device scratch and the (stable) parameter pointers for this set of tensors; rebuilt only when the set
+        changes.  The per-step path below allocates no Python containers beyond two lists: a step that creates hundreds of tuples
+        makes the cyclic garbage collector run inside the next forward pass (measured: +2.3 ms per step)."""
+        old = getattr(self, "_plan_params", None)
+        if old is not None and len(old) == len(params):
+            same = True
+            for i in range(len(params)):
+                if old[i] is not params[i]:
+                    same = False
+                    break
+            if same and self._plan_ptr0 == params[0].data_ptr():
+                return
+        import ctypes as C
+        import numpy as np
+        dev = params[0].device
+        ct, co = [], []
+        for t, p in enumerate(params):
+            nc = (p.numel() + 2047) // 2048
+            ct.append(np.full(nc, t, np.int32))
+            co.append(np.arange(nc, dtype=np.int32))
+        self._chunk_tensor = torch.from_numpy(np.concatenate(ct)).to(dev)
+        self._chunk_off = torch.from_numpy(np.concatenate(co)).to(dev)
+        self._n_chunks = int(self._chunk_tensor.numel())
+        n = len(params)
+        self._table = torch.empty((n, 4), dtype=torch.int64, device=dev)   # device scratch of dbaz_sgd_step
+        self._numels = (C.c_int64 * n)(*[p.numel() for p in params])
+        self._p_ptrs = (C.c_void_p * n)(*[p.data_ptr() for p in params])
+        self._g_ptrs = (C.c_void_p * n)()
+        self._b_ptrs = (C.c_void_p * n)()
+        self._plan_params = list(params)
+        self._plan_ptr0 = params[0].data_ptr()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import ctypes as C
+        from . import _lib
+        if closure is not None or len(self.param_groups) != 1:
+            return super().step(closure)
+        g = self.param_groups[0]
+        params = [p for p in g["params"] if p.grad is not None]
+        ok = bool(params) and not g["nesterov"] and g["dampening"] == 0 and not g.get("maximize", False)
+        if ok:
+            dev = params[0].device
+            for p in params:
+                gr = p.grad
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and gr.dtype == torch.float32 and not gr.is_sparse
+                        and gr.is_contiguous() and p.device == dev):
+                    ok = False
+                    break
+        if not ok:
+            return super().step()
+        self._plan(params)
+        mom = float(g["momentum"])
+        n = len(params)
+        gp, bp = self._g_ptrs, self._b_ptrs
+        for i in range(n):
+            p = params[i]
+            gp[i] = p.grad.data_ptr()      # (new tensors every step: zero_grad sets them to None)
+            if mom != 0.0:                 # (without momentum torch keeps no state: neither do we)
+                st = self.state[p]
+                b = st.get("momentum_buffer")
+                if b is None:
+                    b = st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)  # == torch's first step (buf = d)
+                bp[i] = b.data_ptr()
+        L = _lib.load()
+        with torch.cuda.device(dev):
+            rc = L.dbaz_sgd_step(n, self._p_ptrs, gp, bp if mom != 0.0 else None, self._numels, self._table.data_ptr(),
+                                 self._chunk_tensor.data_ptr(), self._chunk_off.data_ptr(), self._n_chunks, float(g["lr"]), mom,
+                                 float(g["weight_decay"]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != _lib.OK:
+            raise RuntimeError((L.dbaz_trainer_last_error(None) or b"dbaz_sgd_step failed").decode())
+        return None
 
 
 class GenerationLrScheduler:
@@ -161,11 +284,30 @@ def train(model, params, train_dataset, val_dataset, writer, generation, device=
     symmetries = _get(tp, "symmetries")
     model.to(device)
     criterion = AlphaZeroLoss()
-    optimizer = torch.optim.SGD(model.parameters(), lr=_get(tp, "lr"), **dict(_get(tp, "optimizer_params") or {}))
+    # (HipSGD is torch.optim.SGD with a one-launch HIP step() on CUDA parameters; on the CPU it is torch's SGD)
+    optimizer = HipSGD(model.parameters(), lr=_get(tp, "lr"), **dict(_get(tp, "optimizer_params") or {}))
     batch_i = 0
     if generation > 0:
         batch_i = load_checkpoint(_get(nnp, "chkpts_filename").format(generation - 1), model, optimizer, device)
     writer.add_scalar("lr", _get(tp, "lr"), batch_i)
+    # The step is a few hundred kernel launches issued by Python; a cyclic-GC pass over the process's long-lived objects (torch's
+    # modules: ~1e6 of them) in the middle of a forward pass costs 2-3 ms of launch time per step (measured with the profiler:
+    # tools/train_step_time.py).  Freeze what exists now into the permanent generation: collections during training then only look
+    # at the objects the loop itself creates.
+    import gc
+    gc.collect()
+    gc.freeze()
+    try:
+        batch_i = _train_epochs(model, tp, nnp, train_dataset, val_dataset, writer, generation, device, eval_forward, criterion, optimizer,
+                                symmetries, batch_i)
+    finally:
+        gc.unfreeze()
+    save_checkpoint(_get(nnp, "chkpts_filename").format(generation), model, optimizer, batch_i)
+    return batch_i
+
+
+def _train_epochs(model, tp, nnp, train_dataset, val_dataset, writer, generation, device, eval_forward, criterion, optimizer, symmetries,
+                  batch_i):
     for epoch in range(min(2 * generation, _get(tp, "nb_epochs"))):
         model.train(True)
         tr_loss, tr_batches, tr_ok, tr_tot = 0, 0, 0, 1
@@ -220,7 +362,6 @@ def train(model, params, train_dataset, val_dataset, writer, generation, device=
         writer.add_scalars("accuracy", {"v/train": tr_ok / tr_tot, "v/eval": val_ok / val_tot}, batch_i)
         writer.add_scalar("generation", generation, batch_i)
         print("Epoch %d, train loss= %5f, validation loss= %5f" % (epoch, tr_loss / max(1, tr_batches), val_loss), flush=True)
-    save_checkpoint(_get(nnp, "chkpts_filename").format(generation), model, optimizer, batch_i)
     return batch_i
 
 

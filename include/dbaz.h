@@ -271,6 +271,12 @@ int dbaz_dataset_fetch(dbaz_engine *e, int16_t *x, float *pi, float *z);
  * into caller-owned DEVICE buffers boards float32 [n,3,H,W], pi [n,A], z [n,1]; complete on return */
 int dbaz_dataset_batch(dbaz_engine *e, const int32_t *idx, int32_t n, int32_t sym, float *boards_dev,
                        float *pi_dev, float *z_dev);
+/* the same QUEUED on the caller's own stream (a hipStream_t; e.g. torch's current stream) and returning at once: the indices are
+ * validated on the host, nothing is synchronised.  Use this form when the output buffers come from a stream-ordered caching
+ * allocator: dbaz_dataset_batch writes them from the handle's stream, i.e. possibly while work the caller has queued on the
+ * buffers' previous owner is still pending. */
+int dbaz_dataset_batch_on(dbaz_engine *e, const int32_t *idx, int32_t n, int32_t sym, float *boards_dev, float *pi_dev,
+                          float *z_dev, void *stream);
 /* SymmetriesGenerator.forward on DEVICE tensors boards [n,3,H,W] / policies [n,A] (either may be
  * NULL); out-of-place */
 int dbaz_symmetry_apply(dbaz_engine *e, int32_t sym, const float *boards_in_dev, const float *pol_in_dev,
@@ -313,6 +319,24 @@ int dbaz_bn2d_forward(const float *x /*[n][C][H*W]*/, int32_t n, int32_t channel
 int dbaz_bn2d_backward(const float *dout, const float *out, const float *x, int32_t n, int32_t channels, int32_t hw, const float *gamma,
                        const float *save_mean, const float *save_invstd, int32_t relu, float *dx, float *dgamma, float *dbeta,
                        void *workspace, void *stream);
+
+/* ---- AlphaZeroLoss and the SGD update of the optimizer step (nn.py:131-138,179,203-221) --------------------
+ * Stateless, all pointers DEVICE memory, asynchronous on `stream`; errors: dbaz_trainer_last_error(NULL).
+ * dbaz_az_loss: loss_v = mean((z - v)^2), loss_pi = -mean_n(sum_a pi * logp) (nn.py:133-135); loss3 = {loss_v + loss_pi,
+ * loss_pi, loss_v}; d_logp [n][A] / d_v [n] (either may be NULL) receive grad_scale * d(loss_v + loss_pi)/d(.).
+ * workspace: dbaz_az_loss_workspace_bytes() bytes. */
+int64_t dbaz_az_loss_workspace_bytes(void);
+int dbaz_az_loss(const float *logp /*[n][A]*/, const float *v /*[n]*/, const float *pi /*[n][A]*/, const float *z /*[n]*/, int32_t n,
+                 int32_t n_actions, float grad_scale, float *loss3, float *d_logp, float *d_v, void *workspace, void *stream);
+/* torch.optim.SGD.step (dampening 0, no nesterov) for ALL parameter tensors at once: d = g + weight_decay * p;
+ * buf = momentum * buf + d; p -= lr * buf (momentum = 0: p -= lr * d, bufs may be NULL).  params / grads / bufs: HOST arrays of
+ * n_tensors DEVICE pointers (float32, contiguous), numels their element counts; the pointers reach the device as kernel arguments
+ * (no host -> device copy on the stream).  table_dev: n_tensors * 32 bytes of device scratch; chunk c (2048 elements) belongs to
+ * tensor chunk_tensor_dev[c] at chunk index chunk_off_dev[c] within it (device arrays the caller builds once per parameter set).
+ * A zero-initialised buf equals torch's first step. */
+int dbaz_sgd_step(int32_t n_tensors, const void *const *params, const void *const *grads, const void *const *bufs, const int64_t *numels,
+                  void *table_dev, const int32_t *chunk_tensor_dev, const int32_t *chunk_off_dev, int32_t n_chunks, float lr,
+                  float momentum, float weight_decay, void *stream);
 
 #ifdef __cplusplus
 }

@@ -397,3 +397,72 @@ def test_golden_reference_resblocks_in_training_mode(tag):
     for k, v in sth.items():
         assert rel(v, torch.tensor(G[tag + "_s_" + k]).double()) < 2e-6, k
     assert nbt == [1] * (2 * nb)
+
+
+def test_hip_alphazero_loss_vs_torch():
+    """AlphaZeroLoss (nn.py:131-138) forward + backward as HIP kernels (dbaz_az_loss) against torch autograd of the reference's
+    two statements; ragged sizes, an upstream gradient other than 1."""
+    from dotsboxesaz_amd import train as T
+    g = torch.Generator().manual_seed(5)
+    for n, A in ((4096, 98), (37, 32), (1, 200), (515, 98)):
+        logits = torch.randn(n, A, generator=g)
+        p0 = torch.log_softmax(logits, 1).cuda()
+        v0 = torch.tanh(torch.randn(n, 1, generator=g)).cuda()
+        pi = torch.softmax(torch.randn(n, A, generator=g) * 2, 1).cuda()
+        z = (torch.randint(0, 3, (n, 1), generator=g).float() - 1).cuda()
+        res = []
+        for hip in (True, False):
+            p, v = p0.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+            loss, (lpi, lv) = T.AlphaZeroLoss.tensors(p, v, pi, z, hip=hip)
+            (loss * 1.7).backward()
+            res.append((loss.item(), lpi.item(), lv.item(), p.grad.clone(), v.grad.clone()))
+        a, b = res
+        for i in range(3):
+            assert abs(a[i] - b[i]) <= 2e-6 * max(1.0, abs(b[i])), (n, A, i, a[i], b[i])
+        assert torch.allclose(a[3], b[3], rtol=1e-6, atol=1e-9) and torch.allclose(a[4], b[4], rtol=1e-6, atol=1e-9)
+        assert a[4].shape == v0.shape
+    # the module's forward (python floats, nn.py:136-138) goes through the same kernels on CUDA tensors
+    loss, (lpi, lv) = T.AlphaZeroLoss()(p0, v0, pi, z)
+    assert isinstance(lpi, float) and abs(float(loss) - (lpi + lv)) < 1e-6
+
+
+def test_hip_sgd_is_torch_sgd():
+    """HipSGD.step() (one HIP launch over all parameter tensors, dbaz_sgd_step) against torch.optim.SGD with momentum and weight decay
+    (what nn.py:179 builds from configuration.py:62-66): parameters and momentum buffers after 5 steps, a state_dict written by one
+    loaded into the other (the reference's checkpoint format), tensors whose gradient is None, a parameter without momentum."""
+    from dotsboxesaz_amd import train as T
+    g = torch.Generator().manual_seed(9)
+    shapes = [(1,), (7,), (64, 64, 3, 3), (2048,), (2049,), (98, 784), (8,), (3, 5, 7)]
+    for mom, wd in ((0.9, 1e-4), (0.0, 0.0), (0.5, 0.0)):
+        pa = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+        pb = [p.detach().clone().requires_grad_(True) for p in pa]
+        oa = T.HipSGD(pa, lr=3e-2, momentum=mom, weight_decay=wd)
+        ob = torch.optim.SGD(pb, lr=3e-2, momentum=mom, weight_decay=wd)
+        for step in range(5):
+            for i, (a, b) in enumerate(zip(pa, pb)):
+                if i == 4 and step % 2 == 1:
+                    a.grad = b.grad = None                      # a parameter that got no gradient this step
+                    continue
+                gr = torch.randn(a.shape, generator=g).cuda()
+                a.grad, b.grad = gr.clone(), gr.clone()
+            oa.step()
+            ob.step()
+            if step == 2:                                       # checkpoint exchange in both directions (nn.py:292-313)
+                sa, sb = oa.state_dict(), ob.state_dict()
+                assert sa["param_groups"][0]["momentum"] == sb["param_groups"][0]["momentum"] and set(sa["state"]) == set(sb["state"])
+                oa.load_state_dict(sb)
+                ob.load_state_dict(sa)
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (mom, wd, a.shape, float((a - b).abs().max()))
+        if mom:
+            for a, b in zip(pa, pb):
+                # (torch's multi-tensor kernels round g + wd p and momentum buf + d in a slightly different order: an ulp of the
+                # larger operand, 2e-7 at these magnitudes, survives cancellation)
+                assert torch.allclose(oa.state[a]["momentum_buffer"], ob.state[b]["momentum_buffer"], rtol=1e-6, atol=2e-6)
+    # CPU parameters: torch's own step
+    pc = [torch.randn(5, generator=g).requires_grad_(True)]
+    oc = T.HipSGD(pc, lr=0.1, momentum=0.9)
+    pc[0].grad = torch.ones(5)
+    before = pc[0].detach().clone()
+    oc.step()
+    assert torch.allclose(pc[0], before - 0.1)
