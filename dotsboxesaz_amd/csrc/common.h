@@ -130,6 +130,8 @@ struct SearchCfg {
     // full rounds only (self-play stepping with a network evaluator): the evaluation list is cut back to a multiple of eval_round
     // leaves whenever at most eval_defer_max would be left over; the slots behind the cut keep their leaf and ask again next step
     int eval_round, eval_defer_max; // 0: every leaf is evaluated in the step that selected it
+    int gc_lazy;             // node collector: > 0 = recycle dropped nodes only while fewer than this many indices are available
+                             // (dropped nodes then live on as transposition twins until their memory is needed); 0 = two per simulation
 };
 
 // device buffer bundle handed to the tree kernels

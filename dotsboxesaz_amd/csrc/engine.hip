@@ -245,6 +245,7 @@ extern "C" int dbaz_create(const dbaz_config *cfg, dbaz_engine **out)
     for (int i = 0; i < cfg->n_temp; i++) { sc.temp_idx[i] = cfg->temp_idx[i]; sc.temp_val[i] = cfg->temp_val[i]; }
     sc.evaluator = cfg->evaluator; sc.seed = cfg->seed;
     sc.match_play = cfg->match_play ? 1 : 0; sc.evaluator2 = cfg->evaluator2;
+    sc.gc_lazy = (cfg->debug_flags & DBAZ_DBG_LAZY_GC) ? 64 : 0;
     sc.pending = cfg->max_pending_evals > 1 ? cfg->max_pending_evals : 1;
     // self-play in waves follows the reference's bookkeeping (visits added at backup, mcts.py:121-126); the single-tree search
     // of players.AZPlayer defaults to counted virtual visits (dbaz_set_pending changes either)

@@ -602,7 +602,8 @@ __device__ __forceinline__ int select_one(const Geo &g, const SearchCfg &cfg, co
     int cur = root, depth = 0, in_move = -1;
     PoolState q = pool_load(S);
     GcBatch<GC_PER_STEP> gcb; // the collector's share of this simulation: rows requested now, consumed after the descent
-    gc_issue<GC_PER_STEP>(gcb, g, B, slot, pool, q, lane);
+    gcb.k = 0;
+    if (cfg.gc_lazy <= 0 || q.n_free + (g.cap - q.n_nodes) < cfg.gc_lazy) gc_issue<GC_PER_STEP>(gcb, g, B, slot, pool, q, lane);
     int Nself = S->root_N;
     NodeMeta m = load_meta(pool, g, root);
     NodeRows<NPL> R;

@@ -45,6 +45,7 @@ extern "C" {
 /* dbaz_config.debug_flags */
 #define DBAZ_DBG_EARLY_JOIN 1u  /* join the driver pass in front of the network launch (round 2's first order) */
 #define DBAZ_DBG_NO_FALLBACK 2u /* skip the exact-f32 safety-net launch of nn_precision = 1 (timing runs only) */
+#define DBAZ_DBG_LAZY_GC 4u     /* node collector recycles dropped nodes only when fewer than 64 indices are available (A/B) */
 #define DBAZ_RESULT_NONE 2
 
 /* evaluator kinds (what plays the role of async_nn, mcts.py:187) */

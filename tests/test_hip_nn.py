@@ -286,6 +286,25 @@ def _positions(rows, cols, n, seed):
     return X
 
 
+@pytest.mark.parametrize("rows,cols,n", [(3, 3, 600), (9, 9, 300), (4, 2, 400)])
+def test_f16x3_on_trained_like_statistics_other_boards(rows, cols, n):
+    """The same trained-like statistics on the other BASELINE board sizes (3x3: the remainder bodies of the two-cout-tile geometry;
+    9x9: the 7-tile one-cout-tile kernel with the LDS-decoded residual; 4x2: a non-square board), 20 x 64: f16x3 within 1e-4 of
+    torch fp32 (observed ~1e-6), no exact-f32 fallback."""
+    torch.manual_seed(rows * 10 + cols)
+    m = nn_ref.ResNetZeroRef(rows, cols, 64, 20)
+    maxima = nn_ref.trained_like_(m, _positions(rows, cols, 192, 3), 11)
+    X = _positions(rows, cols, n, 4)
+    pr, vr = nn_ref.predict_sync(m, X)
+    e = engine_for(rows, cols, m, n_slots=max(64, n), precision=1)
+    p, v = e.predict(X)
+    c = e.counters()
+    e.close()
+    err = max(np.abs(p - pr).max(), np.abs(v - vr).max())
+    print("trained-like %dx%d 20x64 (activations up to %.0f): f16x3 vs torch fp32 %.2e, fallback %d of %d" % (rows, cols, max(maxima), err, c["f32_fallback_evals"], n))
+    assert err <= 1e-4 and c["f32_fallback_evals"] == 0
+
+
 @pytest.mark.parametrize("seed", [7, 8])
 def test_f16x3_on_trained_like_statistics_20x64(seed):
     """The mode bench.py times, on weights with the statistics of a TRAINED network instead of a fresh one:

@@ -9,5 +9,5 @@ for f in engine nn; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DDBAZ_STAMP $EXTRA_DEFS -c dotsboxesaz_amd/csrc/$f.hip -o build/stamp/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/stamp/libdbaz_hip.so dotsboxesaz_amd/csrc/tree.o build/stamp/engine.o build/stamp/nn.o dotsboxesaz_amd/csrc/replay.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/stamp/libdbaz_hip.so dotsboxesaz_amd/csrc/tree.o build/stamp/engine.o build/stamp/nn.o dotsboxesaz_amd/csrc/replay.o dotsboxesaz_amd/csrc/train.o dotsboxesaz_amd/csrc/buildinfo.o
 echo build/stamp/libdbaz_hip.so
