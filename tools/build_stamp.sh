@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic build of the library with in-kernel cycle stamps in nn.hip only (-DDBAZ_STAMP), into build/stamp/ (not shipped,
+# Diagnostic build of the library with in-kernel cycle stamps in nn.hip only (-DDBAZ_STAMP; EXTRA_DEFS=-DDBAZ_DEBUG adds the A/B variants), into build/stamp/ (not shipped,
 # git-ignored; it travels to the GPU box with the snapshot).  Use with DBAZ_LIB=$PWD/build/stamp/libdbaz_hip.so.
 set -e
 cd "$(dirname "$0")/.."

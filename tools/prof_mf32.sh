@@ -1,5 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the bench step: tools/prof_mf32.sh <tag> <slots> <precision 1|2>
+export DBAZ_LIB=${DBAZ_LIB:-$PWD/dotsboxesaz_amd/libdbaz_hip_debug.so}   # the A/B tilings live in the debug build (python -m dotsboxesaz_amd.build --debug)
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$1
 rm -rf $OUT; mkdir -p $OUT
