@@ -9,9 +9,10 @@
 // Data layout: activations and gradients live in HBM as f32 NHWC -- row = sample * HW + position, 64 channels = 256 B per
 // row -- which is the row layout of the conv kernels' LDS images.  Per layer l (input A[l], l = 0 .. L-1):
 //   forward    Y[l]   = conv3x3(A[l]) + bias                         k_conv_t   (f16x3 MFMA, as the self-play tower)
-//              mean, invstd over the n*HW rows of Y[l]                k_bn_stats / k_bn_stats_fin (f64 sums)
+//              mean, invstd over the n*HW rows of Y[l]                k_conv_t's epilogue (f64 sums per workgroup) + k_bn_stats_fin
 //              A[l+1] = relu(bn(Y[l]) (+ A[l-1] for the second conv of a block))   k_bn_apply
-//   backward   g = dA[l+1] * (A[l+1] > 0); sums of g and g*yhat      k_bn_bwd_sums (-> dgamma, dbeta)
+//   backward   g = dA[l+1] * (A[l+1] > 0); sums of g and g*yhat      epilogue of the k_conv_t that wrote dA[l+1] (top layer: k_bn_bwd_sums)
+//                                                                    + k_bn_bwd_sums_fin (-> dgamma, dbeta)
 //              dY[l] = gamma*invstd*(g - mean(g) - yhat*mean(g*yhat)) k_bn_bwd_apply (also keeps g for the skip path)
 //              dW[l] = sum_rows A[l](row + tap) x dY[l](row)          k_wgrad_h3 (f16x3 MFMA; k_wgrad: exact f32) + k_wgrad_reduce
 //              dA[l] = conv3x3^T(dY[l]) (+ g of the block's end)      k_conv_t with flipped / transposed fragments
@@ -45,6 +46,9 @@ union u128h { f32x4 f; f16x8 h; };
 struct dbaz_trainer {
     int dev = 0, H = 0, W = 0, HW = 0, L = 0, maxN = 0, n = 0;
     int S = 1, Sw = 1, cus = 256;
+#ifdef DBAZ_STAMP
+    unsigned long long *stamps = nullptr; // diagnostic build only
+#endif
     float eps = 1e-5f, momentum = 0.1f;
     size_t conv_lds = 0, wgrad_lds = 0;
     bool have_fwd = false;
@@ -56,7 +60,7 @@ struct dbaz_trainer {
     float *wsc = nullptr;        // [2][L] 2^-sw of the packed weights
     unsigned *amax = nullptr;    // [L+1] bits of max|A[l]|, [L+1] = max|dY| of the layer in flight
     float *mean = nullptr, *invstd = nullptr; // [L][C]
-    double *part = nullptr;      // [RED_BLOCKS][4][C] partial column sums
+    double *part = nullptr;      // partial column sums: [RED_BLOCKS][<= 4][C] rows, or one [2][C] row per workgroup of a conv launch
     double *sums = nullptr;      // [4][C]
     float *wg_part = nullptr;    // [cus][9][C][C]
     unsigned long long *relu_mask = nullptr; // [L][maxN*HW]: sign bits of A[l+1] (64 channels per row)
@@ -192,6 +196,14 @@ __global__ void __launch_bounds__(TT) k_pack_w(PackArgs pa, _Float16 *__restrict
 // wave w owns couts [32 (w & 1), +32) and position tiles [4 (w >> 1), +4); out-of-image taps read a zero region at the
 // lane's own bank slot.  out = acc * 2^-(sx+sw) (+ bias) (+ add).  128 registers: two workgroups per CU.
 // ------------------------------------------------------------------------------------
+// ReLU mask, one bit per element: (row, channel) is set where the layer's output is > 0 -- what the backward pass needs of A --
+// at 8 bytes per row instead of 256; bit 16 e + cq of mask[row] belongs to element e of channel quad cq (four 16-lane ballots)
+__device__ __forceinline__ unsigned quad_mask(unsigned long long m, int cq)
+{
+    const unsigned lo = (unsigned)(m >> cq), hi = (unsigned)(m >> (32 + cq));
+    return (lo & 1u) | ((lo >> 15) & 2u) | ((hi & 1u) << 2) | ((hi >> 13) & 8u);
+}
+
 struct ConvArgs {
     const float *in;          // [n*HW][C]
     const unsigned *in_max;   // bits of max|in|
@@ -200,8 +212,35 @@ struct ConvArgs {
     const float *bias;        // [C] or nullptr
     const float *add;         // [n*HW][C] added to the result, or nullptr
     float *out;               // [n*HW][C]
+    double *stat_part;        // [grid][2][C]: the workgroup's sums of out and out^2 over its rows (the forward convs: BatchNorm's
+                              // batch statistics without another pass over the tensor), or nullptr
+    // input-gradient convs: out (+ add) is dA of the layer below; its BatchNorm backward needs sum(g), sum(g * yhat) over the rows
+    double *bs_part;                      // [grid][2][C], or nullptr
+    const unsigned long long *bs_mask;    // that layer's ReLU mask, one word per row
+    const float *bs_y, *bs_mean, *bs_invstd; // its conv output Y and batch statistics
     int n, S, H, W;
+#ifdef DBAZ_STAMP
+    unsigned long long *stamp_out; // diagnostic build only: [grid][8 waves][8]
+#endif
 };
+
+#ifdef DBAZ_STAMP
+#define TSTAMP(var)                                                                     \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#define TSTAMP_RT(var)                                                                  \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#else
+#define TSTAMP(var) do { } while (0)
+#define TSTAMP_RT(var) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(TT, 4) k_conv_t(ConvArgs a)
 {
@@ -212,6 +251,11 @@ __global__ void __launch_bounds__(TT, 4) k_conv_t(ConvArgs a)
     const int s0 = blockIdx.x * a.S;
     const int ns = min(a.S, a.n - s0);
     if (ns <= 0) return;
+#ifdef DBAZ_STAMP
+    unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, tr0, tr1;
+    TSTAMP_RT(tr0);
+    TSTAMP(ts0);
+#endif
     const int R = ns * HW;
     const int zu = (a.S * HW * S4 + 15) & ~15;
     f32x4 *X4 = reinterpret_cast<f32x4 *>(lds);
@@ -260,8 +304,11 @@ __global__ void __launch_bounds__(TT, 4) k_conv_t(ConvArgs a)
             }
         }
         if (tid < 3 * S4) X4[zu + tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tid == 0) *reinterpret_cast<unsigned *>(X4 + zu + 3 * S4 + (TT / 64) * 2 * C / 2) = 0u; // arrival counter of the epilogue's column sums
     }
+    TSTAMP(ts1);
     __syncthreads();
+    TSTAMP(ts2);
     const int jrow = lane & 15, gq = lane >> 4;
     const int tbase = (wave >> 1) * NTT;
     int vm[NTT];
@@ -337,6 +384,41 @@ __global__ void __launch_bounds__(TT, 4) k_conv_t(ConvArgs a)
     // accumulator layout they were 64-byte pieces of 16 different rows per instruction (13 us of a 55 us launch)
     const float osc = (1.0f / sx) * *a.wsc;
     constexpr int OS = C + 4; // dwords per staged output row: the 16 rows of a tile fall on disjoint banks
+    // what the store pass adds to / reads beside the result is requested HERE, before the barriers: thread tid stores quads
+    // tid + j TT (channel quad tid & 15 of rows (tid >> 4) + 32 j), so its operands are known now and their HBM latency hides
+    // behind the wait for the slowest wave and the staging (fetched inside the store loop they were one latency per pass)
+    constexpr int NST = 256 * (C / 4) / TT;
+    int te = tid;
+    asm volatile("" : "+v"(te)); // the epilogue's addresses are formed HERE: hoisted above the MFMA loop they cost 29 spilled registers
+    const size_t g0 = (size_t)s0 * HW * (C / 4);
+    const int nq = R * (C / 4);
+    f32x4 pa[NST], py[NST];
+    unsigned m4 = 0;
+    if (a.bs_part) {
+        unsigned long long mw[NST];
+#pragma unroll
+        for (int j = 0; j < NST; j++) {
+            const int i = te + j * TT;
+            mw[j] = i < nq ? a.bs_mask[(size_t)s0 * HW + (i >> 4)] : 0ull;
+        }
+        const f32x4 *y4 = reinterpret_cast<const f32x4 *>(a.bs_y) + g0;
+#pragma unroll
+        for (int j = 0; j < NST; j++) {
+            const int i = te + j * TT;
+            py[j] = i < nq ? y4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NST; j++) m4 |= quad_mask(mw[j], te & 15) << (4 * j);
+    }
+    if (a.add) {
+        const f32x4 *add4 = reinterpret_cast<const f32x4 *>(a.add) + g0;
+#pragma unroll
+        for (int j = 0; j < NST; j++) {
+            const int i = te + j * TT;
+            pa[j] = i < nq ? add4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    TSTAMP(ts3);
     __syncthreads();          // every wave has left the MFMA loop
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -349,23 +431,99 @@ __global__ void __launch_bounds__(TT, 4) k_conv_t(ConvArgs a)
         }
     }
     __syncthreads();
+    TSTAMP(ts4);
     {
-        const size_t g0 = (size_t)s0 * HW * (C / 4);
         f32x4 *out4 = reinterpret_cast<f32x4 *>(a.out) + g0;
-        const f32x4 *add4 = a.add ? reinterpret_cast<const f32x4 *>(a.add) + g0 : nullptr;
-        for (int i = tid; i < R * (C / 4); i += TT) {
-            f32x4 v = *reinterpret_cast<const f32x4 *>(lds + (size_t)(i >> 4) * OS + (i & 15) * 4);
-            if (add4) v += add4[i];
-            out4[i] = v;
+        // column sums in f64 beside the store: (out, out^2) for the forward convs -- BatchNorm's batch statistics -- or, for the
+        // input-gradient convs, (g, g * yhat) of the NEXT layer down (g = out where that layer's ReLU let the value through):
+        // what k_bn_stats / k_bn_bwd_sums read the tensor again for (9.8 and 20.3 us per layer)
+        double st[2][4] = {};
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu;
+        if (a.bs_part) {
+            mu = *reinterpret_cast<const f32x4 *>(a.bs_mean + (te & 15) * 4);
+            is = *reinterpret_cast<const f32x4 *>(a.bs_invstd + (te & 15) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NST; j++) {
+            const int i = te + j * TT;
+            if (i < nq) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(lds + (size_t)(i >> 4) * OS + (i & 15) * 4);
+                if (a.add) v += pa[j];
+                out4[i] = v;
+                if (a.stat_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { const double d = v[e]; st[0][e] += d; st[1][e] += d * d; }
+                }
+                if (a.bs_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float g = ((m4 >> (4 * j + e)) & 1u) ? v[e] : 0.0f;
+                        const float yh = (py[j][e] - mu[e]) * is[e];
+                        st[0][e] += (double)g;
+                        st[1][e] += (double)g * (double)yh;
+                    }
+                }
+            }
+        }
+        double *sp = a.stat_part ? a.stat_part : a.bs_part;
+        if (sp) {
+            // the thread's channel quad is tid & 15 on every pass (TT is a multiple of 16): the wave's four row lanes of a quad
+            // are added up by two exchanges, lanes 0..15 leave the WAVE's sums in its own LDS slot, and the last wave to arrive
+            // (an LDS counter, no workgroup barrier: one through LDS behind two barriers cost 6.8 us per launch -- a
+            // workgroup's tail is the launch's critical path twice over) adds the 8 slots in wave order and writes the
+            // workgroup's row
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    st[k][e] += __shfl_xor(st[k][e], 16);
+                    st[k][e] += __shfl_xor(st[k][e], 32);
+                }
+            double *slots = reinterpret_cast<double *>(X4 + zu + 3 * S4);       // [8 waves][2][C]
+            unsigned *arrived = reinterpret_cast<unsigned *>(slots + (TT / 64) * 2 * C);
+            if (lane < 16) {
+                double *o = slots + wave * 2 * C + lane * 4;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    *reinterpret_cast<double2 *>(o + k * C) = make_double2(st[k][0], st[k][1]);
+                    *reinterpret_cast<double2 *>(o + k * C + 2) = make_double2(st[k][2], st[k][3]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            unsigned old = 0;
+            if (lane == 0) old = atomicAdd(arrived, 1u);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == TT / 64 - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                double2 v = {0.0, 0.0};
+#pragma unroll
+                for (int w = 0; w < TT / 64; w++) {
+                    const double2 x = *reinterpret_cast<const double2 *>(slots + w * 2 * C + lane * 2);
+                    v.x += x.x; v.y += x.y;
+                }
+                *reinterpret_cast<double2 *>(sp + (size_t)blockIdx.x * 2 * C + lane * 2) = v;
+            }
         }
     }
+#ifdef DBAZ_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSTAMP(ts5);
+    TSTAMP_RT(tr1);
+    if (a.stamp_out && lane == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *o = a.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = ts3 - ts2; o[3] = ts4 - ts3; o[4] = ts5 - ts4; o[5] = tr0; o[6] = tr1;
+        o[7] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
 // column sums over the rows of [M][C] tensors, f64: the workgroup's 512 threads = 32 row lanes x 16 channel quads write one
-// partial per workgroup; a one-workgroup kernel (colsum_total) adds the partials up.  (Letting the last workgroup to arrive
-// do that -- __threadfence + a device-scope counter -- made these kernels 4-6x slower: every fence writes the XCD's dirty L2
-// lines back, and these kernels have just written 50 MB.)
+// partial row per workgroup; the *_fin kernels (colsum_total) add the rows up.
 // ------------------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ void block_colsum_store(double (&s)[K][4], double *part /*[blocks][K][C]*/)
@@ -385,7 +543,8 @@ __device__ __forceinline__ void block_colsum_store(double (&s)[K][4], double *pa
     }
 }
 
-// the partials' totals of channel blockIdx.x (grid: C workgroups of 512 threads, one partial lane each): tot[k]
+// the partial rows' totals of channel blockIdx.x (grid: C workgroups of 512 threads, one row lane each): tot[k].  One level, no
+// last-arriver: a __threadfence costs ~20 us here too (it writes back what the previous kernel left dirty in the XCD's L2).
 #define FIN_BLOCKS TC
 template <int K>
 __device__ __forceinline__ void colsum_total(const double *part, int nparts, double *tot /* LDS [K] */)
@@ -422,24 +581,6 @@ __device__ __forceinline__ void block_atomic_max(float mx, unsigned *amax)
     }
 }
 
-// partials of sum(y), sum(y^2) over the rows
-__global__ void __launch_bounds__(TT) k_bn_stats(const f32x4 *__restrict__ y4, long long M, double *part)
-{
-    double s[2][4] = {};
-    const int cq = threadIdx.x & 15;
-    const long long rs = (long long)gridDim.x * 32;
-    for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 4); r < M; r += 4 * rs) {
-        f32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = r + u * rs < M ? y4[(r + u * rs) * 16 + cq] : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) { const double d = v[u][e]; s[0][e] += d; s[1][e] += d * d; }
-    }
-    block_colsum_store<2>(s, part);
-}
-
 // -> batch mean / invstd and the running statistics (BatchNorm2d training mode: momentum 0.1, unbiased running variance)
 __global__ void __launch_bounds__(TT) k_bn_stats_fin(const double *part, int nparts, long long M, float eps, float momentum, float *mean,
                                                      float *invstd, float *run_mean, float *run_var)
@@ -461,15 +602,7 @@ __global__ void __launch_bounds__(TT) k_bn_stats_fin(const double *part, int npa
     }
 }
 
-// A_out = relu(gamma * (y - mean) * invstd + beta (+ res)); tracks max(A_out)
-// one bit per element: (row, channel) is set where the layer's output is > 0 -- what the backward pass needs of A (the ReLU mask)
-// at 8 bytes per row instead of 256; bit 16 e + cq of mask[row] belongs to element e of channel quad cq (four 16-lane ballots)
-__device__ __forceinline__ unsigned quad_mask(unsigned long long m, int cq)
-{
-    const unsigned lo = (unsigned)(m >> cq), hi = (unsigned)(m >> (32 + cq));
-    return (lo & 1u) | ((lo >> 15) & 2u) | ((hi & 1u) << 2) | ((hi >> 13) & 8u);
-}
-
+// A_out = relu(gamma * (y - mean) * invstd + beta (+ res)); tracks max(A_out); writes the ReLU mask (quad_mask)
 __global__ void __launch_bounds__(256) k_bn_apply(const f32x4 *__restrict__ y4, const f32x4 *__restrict__ res4, f32x4 *__restrict__ out4,
                                                   long long n4, const float *mean, const float *invstd, const float *gamma,
                                                   const float *beta, unsigned *amax, unsigned long long *__restrict__ mask)
@@ -547,7 +680,7 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_sums_fin(const double *part, int 
 }
 
 // backward, pass 2: dY = gamma * invstd * (g - sum(g)/M - yhat * sum(g*yhat)/M); keeps g (skip path of a block's end);
-// tracks max|dY|; partials of sum(dY) (the conv bias gradient: k_dbias_fin)
+// tracks max|dY|; partials of sum(dY) (the conv bias gradient: totalled by k_wgrad_reduce's last workgroups)
 __global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ dA4, const unsigned long long *__restrict__ mask, const f32x4 *__restrict__ y4,
                                                      long long M, const float *mean, const float *invstd, const float *gamma,
                                                      const double *sums, f32x4 *__restrict__ dY4, f32x4 *__restrict__ g4,
@@ -582,13 +715,6 @@ __global__ void __launch_bounds__(TT) k_bn_bwd_apply(const f32x4 *__restrict__ d
     }
     block_atomic_max(mx, amax);
     block_colsum_store<1>(s, part);
-}
-
-__global__ void __launch_bounds__(TT) k_dbias_fin(const double *part, int nparts, float *dbias)
-{
-    __shared__ double tot[1];
-    colsum_total<1>(part, nparts, tot);
-    if (threadIdx.x == 0) dbias[blockIdx.x] = (float)tot[0];
 }
 
 // ------------------------------------------------------------------------------------
@@ -902,10 +1028,24 @@ __global__ void __launch_bounds__(TT, 2) k_wgrad_h3(const float *__restrict__ ac
 }
 
 // sums the workgroups' partial gradients (f64) and writes torch's [cout][cin][3][3]: 64 outputs x 4 partial lanes per block
-__global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ part, int nparts, float *__restrict__ dw)
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ part, int nparts, float *__restrict__ dw,
+                                                      const double *__restrict__ bias_part, int bias_nparts, float *__restrict__ dbias)
 {
     __shared__ double red[4][64];
     const int o = threadIdx.x & 63, j = threadIdx.x >> 6;
+    if (blockIdx.x >= 9 * TC * TC / 64) {
+        // the last C workgroups: the conv bias gradient of channel c = the total of k_bn_bwd_apply's partial sums of dY (a launch
+        // of its own before: 4.8 us per layer)
+        const int c = blockIdx.x - 9 * TC * TC / 64;
+        double v = 0.0;
+        for (int bb = threadIdx.x; bb < bias_nparts; bb += 256) v += bias_part[(size_t)bb * TC + c];
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_xor(v, sh);
+        if (o == 0) red[j][0] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) dbias[c] = (float)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
+        return;
+    }
     const int i = blockIdx.x * 64 + o; // (tap * C + cin) * C + cout
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int b = j;
@@ -964,7 +1104,7 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     {
         const int S4 = (TC + 8) / 4;
         const int zu = (t->S * t->HW * S4 + 15) & ~15;
-        t->conv_lds = (size_t)(zu + 3 * S4) * 16;
+        t->conv_lds = (size_t)(zu + 3 * S4) * 16 + (size_t)(TT / 64) * 2 * TC * 8 + 16; // image + zero rows + the epilogue's column-sum slots
         t->wgrad_lds = wg_lds_bytes(t->Sw, t->H, t->W);
         t->Swh = 1;
         while ((t->Swh + 1) * t->HW <= 208 && wh_lds_bytes(t->Swh + 1, t->H, t->W) <= 150 * 1024) t->Swh++;
@@ -988,10 +1128,13 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     alloc((void **)&t->amax, (size_t)(t->L + 2) * 4);
     alloc((void **)&t->mean, (size_t)t->L * TC * 4);
     alloc((void **)&t->invstd, (size_t)t->L * TC * 4);
-    alloc((void **)&t->part, (size_t)RED_BLOCKS * 4 * TC * 8);
+    alloc((void **)&t->part, std::max((size_t)RED_BLOCKS * 4, (size_t)(t->maxN / t->S + 1) * 2) * TC * 8);
     alloc((void **)&t->sums, (size_t)4 * TC * 8);
     alloc((void **)&t->wg_part, (size_t)t->cus * 9 * TC * TC * 4);
     alloc((void **)&t->relu_mask, (size_t)t->L * t->maxN * t->HW * 8);
+#ifdef DBAZ_STAMP
+    alloc((void **)&t->stamps, (size_t)(t->maxN / t->S + 1) * 64 * 8);
+#endif
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad_h3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_h3_lds);
@@ -1004,6 +1147,16 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     *out = t;
     return DBAZ_OK;
 }
+
+#ifdef DBAZ_STAMP
+extern "C" int dbaz_debug_trainer_stamps(dbaz_trainer *t, unsigned long long *out, int n_wg)
+{
+    if (!t || !out) return DBAZ_EINVAL;
+    (void)hipDeviceSynchronize();
+    const int have = t->maxN / t->S + 1;
+    return hipMemcpy(out, t->stamps, (size_t)std::min(n_wg, have) * 64 * 8, hipMemcpyDeviceToHost) == hipSuccess ? DBAZ_OK : DBAZ_ESTATE;
+}
+#endif
 
 static int red_blocks(long long M) { return (int)std::max(1LL, std::min((long long)RED_BLOCKS, (M + 31) / 32)); }
 
@@ -1029,18 +1182,19 @@ extern "C" int dbaz_trainer_forward(dbaz_trainer *t, int32_t n, const float *x, 
     for (int l = 0; l < L; l++) pa.w[l] = conv_w[l];
     hipLaunchKernelGGL(k_pack_w, dim3(L, 2), dim3(TT), 0, s, pa, t->wpk, t->wsc, L);
     const int grid = (n + t->S - 1) / t->S;
-    const int rb = red_blocks(M);
     const long long n4 = M * 16;
     const int ab = (int)std::min<long long>((n4 + 255) / 256, 1024);
     for (int l = 0; l < L; l++) {
-        ConvArgs ca;
+        ConvArgs ca = {};
         ca.in = t->A + ae * l; ca.in_max = t->amax + l;
         ca.wpk = t->wpk + (size_t)l * TC * TC * 9 * 2; ca.wsc = t->wsc + l;
-        ca.bias = conv_b[l]; ca.add = nullptr; ca.out = t->Y + ae * l;
+        ca.bias = conv_b[l]; ca.add = nullptr; ca.out = t->Y + ae * l; ca.stat_part = t->part;
         ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
+#ifdef DBAZ_STAMP
+        ca.stamp_out = t->stamps;
+#endif
         hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
-        hipLaunchKernelGGL(k_bn_stats, dim3(rb), dim3(TT), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l), M, t->part);
-        hipLaunchKernelGGL(k_bn_stats_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, M, t->eps, t->momentum, t->mean + l * TC,
+        hipLaunchKernelGGL(k_bn_stats_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, grid, M, t->eps, t->momentum, t->mean + l * TC,
                            t->invstd + l * TC, run_mean ? run_mean[l] : nullptr, run_var ? run_var[l] : nullptr);
         hipLaunchKernelGGL(k_bn_apply, dim3(ab), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(t->Y + ae * l),
                            (l & 1) ? reinterpret_cast<const f32x4 *>(t->A + ae * (l - 1)) : nullptr,
@@ -1081,12 +1235,15 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
         const f32x4 *dA4 = reinterpret_cast<const f32x4 *>(t->dA[cur]);
         const unsigned long long *ao4 = t->relu_mask + (size_t)l * t->maxN * HW; // sign bits of A[l + 1]
         const f32x4 *y4 = reinterpret_cast<const f32x4 *>(t->Y + ae * l);
-        hipLaunchKernelGGL(k_bn_bwd_sums, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, t->part);
-        hipLaunchKernelGGL(k_bn_bwd_sums_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, t->sums, g_bn_b[l], g_bn_w[l], dymax);
+        // sum(g), sum(g * yhat): left in t->part by the conv that produced dA (the layer above's input-gradient conv); the top
+        // layer's dA comes from the caller
+        if (l == L - 1)
+            hipLaunchKernelGGL(k_bn_bwd_sums, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, t->part);
+        hipLaunchKernelGGL(k_bn_bwd_sums_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, l == L - 1 ? rb : grid, t->sums, g_bn_b[l],
+                           g_bn_w[l], dymax);
         hipLaunchKernelGGL(k_bn_bwd_apply, dim3(rb), dim3(TT), 0, s, dA4, ao4, y4, M, t->mean + l * TC, t->invstd + l * TC, bn_w[l],
                            t->sums, reinterpret_cast<f32x4 *>(t->dY), (l & 1) ? reinterpret_cast<f32x4 *>(t->G) : (f32x4 *)nullptr,
                            dymax, t->part);
-        hipLaunchKernelGGL(k_dbias_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, rb, g_conv_b[l]);
         if (t->wgrad_h3 && t->W == 7)
             hipLaunchKernelGGL((k_wgrad_h3<8>), dim3(wg), dim3(TT), t->wgrad_h3_lds, s, t->A + ae * l, t->dY, t->amax + l, dymax, n, Sw, t->H,
                                t->W, t->wg_part);
@@ -1095,13 +1252,20 @@ extern "C" int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, con
                                t->W, t->wg_part);
         else
             hipLaunchKernelGGL(k_wgrad, dim3(wg), dim3(TT), t->wgrad_lds, s, t->A + ae * l, t->dY, n, Sw, t->H, t->W, t->wg_part);
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3(9 * TC * TC / 64), dim3(256), 0, s, t->wg_part, wg, g_conv_w[l]);
-        ConvArgs ca;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(9 * TC * TC / 64 + TC), dim3(256), 0, s, t->wg_part, wg, g_conv_w[l], t->part, rb, g_conv_b[l]);
+        ConvArgs ca = {};
         ca.in = t->dY; ca.in_max = dymax;
         ca.wpk = t->wpk + ((size_t)L + l) * TC * TC * 9 * 2; ca.wsc = t->wsc + L + l;
-        ca.bias = nullptr; ca.out = t->dA[1 - cur];
+        ca.bias = nullptr; ca.out = t->dA[1 - cur]; ca.stat_part = nullptr;
+        if (l > 0) {
+            ca.bs_part = t->part; ca.bs_mask = t->relu_mask + (size_t)(l - 1) * t->maxN * HW; ca.bs_y = t->Y + ae * (l - 1);
+            ca.bs_mean = t->mean + (l - 1) * TC; ca.bs_invstd = t->invstd + (l - 1) * TC;
+        }
         ca.add = (l & 1) ? nullptr : t->G; // the input of a block's first conv is also the block's skip input: + g of its end
         ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
+#ifdef DBAZ_STAMP
+        ca.stamp_out = t->stamps;
+#endif
         hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         cur = 1 - cur;
     }
