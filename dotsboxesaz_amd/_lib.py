@@ -28,9 +28,24 @@ SYMBOLS = [
     "dbaz_replay_rows_clear", "dbaz_dataset_select", "dbaz_dataset_begin", "dbaz_dataset_add_rows", "dbaz_dataset_finish", "dbaz_dataset_fetch", "dbaz_dataset_batch", "dbaz_dataset_batch_on",
     "dbaz_symmetry_apply", "dbaz_symmetry_table",
     "dbaz_trainer_last_error", "dbaz_trainer_create", "dbaz_trainer_destroy", "dbaz_trainer_forward", "dbaz_trainer_backward",
+    "dbaz_trainer_net_forward", "dbaz_trainer_net_backward",
     "dbaz_bn2d_workspace_bytes", "dbaz_bn2d_forward", "dbaz_bn2d_backward",
     "dbaz_az_loss_workspace_bytes", "dbaz_az_loss", "dbaz_sgd_step",
 ]
+
+
+class NetTensors(C.Structure):
+    """dbaz_net_tensors (include/dbaz.h): device pointers to a ResNetZero's parameters -- or to where their gradients go."""
+    _fields_ = [(k, C.c_void_p) for k in (
+        "bn_input_w", "bn_input_b", "conv0_w", "conv0_b", "bn0_w", "bn0_b", "blk_conv_w", "blk_conv_b", "blk_bn_w", "blk_bn_b",
+        "ph_conv_w", "ph_conv_b", "ph_bn_w", "ph_bn_b", "ph_fc_w", "ph_fc_b", "vh_conv_w", "vh_conv_b", "vh_bn_w", "vh_bn_b",
+        "vh_fc0_w", "vh_fc0_b", "vh_fc1_w", "vh_fc1_b")]
+
+
+class NetRunning(C.Structure):
+    """dbaz_net_running: the BatchNorm layers' running statistics."""
+    _fields_ = [(k, C.c_void_p) for k in ("bn_input_mean", "bn_input_var", "bn0_mean", "bn0_var", "blk_mean", "blk_var", "ph_mean", "ph_var",
+                                          "vh_mean", "vh_var")]
 
 
 class Config(C.Structure):
@@ -136,6 +151,8 @@ def load():
     L.dbaz_trainer_destroy.restype = None
     L.dbaz_trainer_forward.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.dbaz_trainer_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.dbaz_trainer_net_forward.argtypes = [vp, i32, vp, C.POINTER(NetTensors), C.POINTER(NetRunning), i32, i32, i32, vp, vp, vp]
+    L.dbaz_trainer_net_backward.argtypes = [vp, vp, vp, vp, C.POINTER(NetTensors), C.POINTER(NetTensors), vp]
     L.dbaz_bn2d_workspace_bytes.argtypes = [i32]
     L.dbaz_bn2d_forward.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp]
     L.dbaz_bn2d_backward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]

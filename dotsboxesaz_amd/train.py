@@ -23,11 +23,12 @@ def _get(d, k, default=None):
     return getattr(d, k, default)
 
 
-def training_forward(model, x, hip_tower=None):
+def training_forward(model, x, hip_tower=None, hip_heads=None):
     """(log_softmax policy, tanh value) of a `nn.ResNetZero` / `nn.SimpleNN` container, in the
     reference's operation order (nn.py:23-28,48-57,81-86,98-104,117-122; dots_boxes_nn.py:85-98).
     hip_tower: None = the HIP residual tower whenever it applies (training mode, CUDA tensor, 64 channels),
-    False = torch's, True = required."""
+    False = torch's, True = required.  hip_heads: None = bn_input, conv0 and both heads on the HIP kernels too whenever the tower
+    is and the model has the shipped stem / head shape (train_tower.net_supported), False = those layers on torch, True = required."""
     if getattr(model, "kind", None) == "simplenn":
         for i in range(5):
             x = getattr(model, "bn%d" % i)(F.relu(getattr(model, "conv%d" % i)(x)))
@@ -42,6 +43,11 @@ def training_forward(model, x, hip_tower=None):
     if hip_tower is True and not use_hip:
         raise RuntimeError("the HIP training tower needs a 64-channel ResNetZero in training mode on a CUDA tensor")
     r, ph, vh = model.resnet, model.policy_head, model.value_head
+    if use_hip and hip_heads is not False and train_tower.net_supported(model, x):
+        # the whole network -- stem, residual tower, heads -- forward and backward on csrc/train.hip (two C calls)
+        return train_tower.network_forward(model, x)
+    if hip_heads is True:
+        raise RuntimeError("the HIP stem / heads need the shipped ResNetZero shape (3 input planes, 16 head channels) in training mode")
     if use_hip:
         # residual blocks and every BatchNorm2d (+ its ReLU) on csrc/train.hip; convs 3->64 / 1x1 and the FCs on torch
         bn = train_tower.batch_norm_train

@@ -77,6 +77,31 @@ class TowerTrainer:
         return gx
 
 
+    # ---- the whole network (stem, tower, heads): dbaz_trainer_net_forward / _backward
+    def net_forward(self, x, tensors, running, head_channels, n_actions, value_fc):
+        """x [n,3,H,W] -> (logp [n,A], v [n,1], generation).  tensors / running: _NetArgs (keep them alive until the call returns)."""
+        n = x.shape[0]
+        if n > self.max_batch:
+            raise TrainerError("batch %d exceeds the handle's max_batch %d" % (n, self.max_batch))
+        logp = torch.empty((n, n_actions), dtype=torch.float32, device=x.device)
+        v = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            self._ck(self._L.dbaz_trainer_net_forward(self.h, n, x.data_ptr(), C.byref(tensors.struct), C.byref(running.struct), head_channels,
+                                                      n_actions, value_fc, logp.data_ptr(), v.data_ptr(), C.c_void_p(stream)))
+        self.generation += 1
+        return logp, v, self.generation
+
+    def net_backward(self, x, d_logp, d_v, tensors, grads, generation=None):
+        if generation is not None and generation != self.generation:
+            raise TrainerError("backward of forward pass #%d, but the trainer handle now holds pass #%d: a handle keeps the activations "
+                               "of ONE forward pass" % (generation, self.generation))
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            self._ck(self._L.dbaz_trainer_net_backward(self.h, x.data_ptr(), d_logp.data_ptr(), d_v.data_ptr(), C.byref(tensors.struct),
+                                                       C.byref(grads.struct), C.c_void_p(stream)))
+
+
 class _TowerFn(torch.autograd.Function):
     """autograd node around the two C calls.  args: trainer, running stats (lists), x, then 4 tensors per layer
     (conv.weight, conv.bias, bn.weight, bn.bias) in layer order."""
@@ -206,3 +231,118 @@ def batch_norm_train(bn, x, relu=False):
     and bn_input(x) of nn.py:117."""
     bn.num_batches_tracked += 1
     return _BNFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+
+
+# ---- the whole network of the optimizer step on csrc/train.hip: p, v = model(boards) (nn.py:108-122) and its backward
+_NET_SINGLE = ("bn_input_w", "bn_input_b", "conv0_w", "conv0_b", "bn0_w", "bn0_b", "ph_conv_w", "ph_conv_b", "ph_bn_w", "ph_bn_b", "ph_fc_w",
+               "ph_fc_b", "vh_conv_w", "vh_conv_b", "vh_bn_w", "vh_bn_b", "vh_fc0_w", "vh_fc0_b", "vh_fc1_w", "vh_fc1_b")
+_NET_BLOCK = ("blk_conv_w", "blk_conv_b", "blk_bn_w", "blk_bn_b")
+
+
+def _net_parameters(model):
+    """The parameters in dbaz_net_tensors order: the 20 single tensors, then per layer (conv.weight, conv.bias, bn.weight, bn.bias)."""
+    r, ph, vh = model.resnet, model.policy_head, model.value_head
+    single = [model.bn_input.weight, model.bn_input.bias, r.conv0.weight, r.conv0.bias, r.bn0.weight, r.bn0.bias,
+              ph.conv0.weight, ph.conv0.bias, ph.bn0.weight, ph.bn0.bias, ph.fc.weight, ph.fc.bias,
+              vh.conv0.weight, vh.conv0.bias, vh.bn0.weight, vh.bn0.bias, vh.fc0.weight, vh.fc0.bias, vh.fc1.weight, vh.fc1.bias]
+    layers = []
+    for b in r.resblocks:
+        for conv, bn in ((b.conv1, b.bn1), (b.conv2, b.bn2)):
+            layers += [conv.weight, conv.bias, bn.weight, bn.bias]
+    return single, layers
+
+
+class _NetArgs:
+    """A dbaz_net_tensors over a list of tensors (keeps the pointer arrays alive)."""
+
+    def __init__(self, single, layers):
+        st = _lib.NetTensors()
+        for name, t in zip(_NET_SINGLE, single):
+            setattr(st, name, t.data_ptr())
+        L = len(layers) // 4
+        self._arrays = [_ptr_array([layers[4 * l + k] for l in range(L)]) for k in range(4)]
+        for name, arr in zip(_NET_BLOCK, self._arrays):
+            setattr(st, name, C.cast(arr, C.c_void_p))
+        self.struct = st
+
+
+class _NetRunning:
+    def __init__(self, model):
+        r, ph, vh = model.resnet, model.policy_head, model.value_head
+        st = _lib.NetRunning()
+        for name, t in (("bn_input_mean", model.bn_input.running_mean), ("bn_input_var", model.bn_input.running_var),
+                        ("bn0_mean", r.bn0.running_mean), ("bn0_var", r.bn0.running_var), ("ph_mean", ph.bn0.running_mean),
+                        ("ph_var", ph.bn0.running_var), ("vh_mean", vh.bn0.running_mean), ("vh_var", vh.bn0.running_var)):
+            setattr(st, name, t.data_ptr())
+        bns = [bn for b in r.resblocks for bn in (b.bn1, b.bn2)]
+        self._arrays = [_ptr_array([bn.running_mean for bn in bns]), _ptr_array([bn.running_var for bn in bns])]
+        st.blk_mean = C.cast(self._arrays[0], C.c_void_p)
+        st.blk_var = C.cast(self._arrays[1], C.c_void_p)
+        self.struct = st
+        self.counters = [model.bn_input.num_batches_tracked, r.bn0.num_batches_tracked, ph.bn0.num_batches_tracked,
+                         vh.bn0.num_batches_tracked] + [bn.num_batches_tracked for bn in bns]
+
+
+class _NetFn(torch.autograd.Function):
+    """autograd node around dbaz_trainer_net_forward / _backward.  args: trainer, running statistics, geometry, x, then the
+    parameters in _net_parameters order."""
+
+    @staticmethod
+    def forward(ctx, trainer, running, geo, x, *params):
+        ps = [p.detach().contiguous() for p in params]
+        tensors = _NetArgs(ps[:len(_NET_SINGLE)], ps[len(_NET_SINGLE):])
+        xc = x.detach().contiguous().float()
+        logp, v, gen = trainer.net_forward(xc, tensors, running, *geo)
+        ctx.trainer, ctx.tensors, ctx.ps, ctx.x, ctx.generation = trainer, tensors, ps, xc, gen
+        return logp, v
+
+    @staticmethod
+    def backward(ctx, d_logp, d_v):
+        dev = ctx.x.device
+        grads = [torch.empty(p.shape, dtype=torch.float32, device=dev) for p in ctx.ps]
+        g = _NetArgs(grads[:len(_NET_SINGLE)], grads[len(_NET_SINGLE):])
+        ctx.trainer.net_backward(ctx.x, d_logp.contiguous().float(), d_v.contiguous().float(), ctx.tensors, g, generation=ctx.generation)
+        return (None, None, None, None) + tuple(grads)
+
+
+def net_supported(model, x):
+    """The whole-network HIP pass covers what `supported` covers plus the shipped stem and heads: 3 input planes, 16 head channels,
+    1x1 head convs with bias, the heads' fc layers with bias, BatchNorm2d with torch's defaults everywhere."""
+    if not supported(model, x):
+        return False
+    r, ph, vh = model.resnet, getattr(model, "policy_head", None), getattr(model, "value_head", None)
+    bn_in = getattr(model, "bn_input", None)
+    if ph is None or vh is None or bn_in is None or x.dim() != 4 or x.shape[1] != 3:
+        return False
+    H, W = x.shape[2], x.shape[3]
+
+    def conv1x1(c):
+        return (c.in_channels == 64 and c.out_channels == 16 and tuple(c.kernel_size) == (1, 1) and tuple(c.stride) == (1, 1)
+                and tuple(c.padding) == (0, 0) and c.groups == 1 and c.bias is not None and c.weight.dtype == torch.float32)
+
+    c0 = r.conv0
+    stem = (c0.in_channels == 3 and tuple(c0.kernel_size) == (3, 3) and tuple(c0.padding) == (1, 1) and tuple(c0.stride) == (1, 1)
+            and tuple(c0.dilation) == (1, 1) and c0.groups == 1 and c0.bias is not None and bn_in.num_features == 3)
+    fcs = (ph.fc.in_features == 16 * H * W and vh.fc0.in_features == 16 * H * W and vh.fc1.in_features == vh.fc0.out_features
+           and vh.fc1.out_features == 1 and ph.fc.bias is not None and vh.fc0.bias is not None and vh.fc1.bias is not None
+           and ph.fc.out_features <= 4096 and vh.fc0.out_features <= 256)
+    return bool(stem and conv1x1(ph.conv0) and conv1x1(vh.conv0) and fcs and all(_bn_ok(b) for b in (bn_in, r.bn0, ph.bn0, vh.bn0)))
+
+
+def network_forward(model, x, trainer=None):
+    """(log_softmax policy [n, A], tanh value [n, 1]) of a ResNetZero in training mode, every layer on csrc/train.hip; differentiable
+    with respect to all parameters (not x).  One handle holds ONE forward pass (see resblocks_forward)."""
+    r = model.resnet
+    H, W = x.shape[2], x.shape[3]
+    tr = trainer
+    if tr is None:
+        key = (id(model), H, W, len(r.resblocks), x.device.index or 0)
+        tr = _trainers.get(key)
+        if tr is None or tr.max_batch < x.shape[0]:
+            tr = TowerTrainer(H - 1, W - 1, 64, len(r.resblocks), max(int(x.shape[0]), 1), x.device.index or 0)
+            _trainers[key] = tr
+    single, layers = _net_parameters(model)
+    running = _NetRunning(model)
+    torch._foreach_add_(running.counters, 1)   # BatchNorm2d.forward: num_batches_tracked += 1
+    geo = (16, model.policy_head.fc.out_features, model.value_head.fc0.out_features)
+    return _NetFn.apply(tr, running, geo, x, *single, *layers)

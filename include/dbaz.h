@@ -308,6 +308,34 @@ int dbaz_trainer_backward(dbaz_trainer *t, const float *grad_out, const float *c
                           float *const *g_conv_w, float *const *g_conv_b, float *const *g_bn_w, float *const *g_bn_b,
                           void *stream);
 
+/* ---- the whole network of the optimizer step: `p, v = self.model(boards)` and `loss.backward()` of
+ * NeuralNetWrapper.train (nn.py:203-221) for a ResNetZero under model.train(True) -- bn_input, conv0 + bn0 (nn.py:19-21,48-50), the
+ * residual tower, both heads (nn.py:74-105: conv 1x1 + bn + ReLU + fc (+ ReLU + fc1) -> log_softmax / tanh) -- on one
+ * dbaz_trainer handle.  A dbaz_net_tensors holds DEVICE pointers to the parameters (or, in the backward call, to where their
+ * gradients are WRITTEN), shapes as torch's; blk_* are HOST arrays [2*blocks] as in dbaz_trainer_forward.  Head channels: 16. */
+typedef struct dbaz_net_tensors {
+    float *bn_input_w, *bn_input_b;                                    /* [3] */
+    float *conv0_w, *conv0_b;                                          /* [64][3][3][3], [64] */
+    float *bn0_w, *bn0_b;                                              /* [64] */
+    float *const *blk_conv_w, *const *blk_conv_b, *const *blk_bn_w, *const *blk_bn_b;
+    float *ph_conv_w, *ph_conv_b, *ph_bn_w, *ph_bn_b;                  /* [16][64][1][1], [16], [16], [16] */
+    float *ph_fc_w, *ph_fc_b;                                          /* [A][16*H*W], [A] */
+    float *vh_conv_w, *vh_conv_b, *vh_bn_w, *vh_bn_b;
+    float *vh_fc0_w, *vh_fc0_b;                                        /* [value_fc][16*H*W], [value_fc] */
+    float *vh_fc1_w, *vh_fc1_b;                                        /* [1][value_fc], [1] */
+} dbaz_net_tensors;
+typedef struct dbaz_net_running { /* BatchNorm running statistics, updated in place (any pointer may be NULL) */
+    float *bn_input_mean, *bn_input_var, *bn0_mean, *bn0_var;
+    float *const *blk_mean, *const *blk_var;                           /* HOST arrays [2*blocks] or NULL */
+    float *ph_mean, *ph_var, *vh_mean, *vh_var;
+} dbaz_net_running;
+/* x float32 [n][3][H][W] -> logp [n][n_actions] (log_softmax), v [n] (tanh).  `running` may be NULL. */
+int dbaz_trainer_net_forward(dbaz_trainer *t, int32_t n, const float *x, const dbaz_net_tensors *params, const dbaz_net_running *running,
+                             int32_t head_channels, int32_t n_actions, int32_t value_fc, float *logp, float *v, void *stream);
+/* backward of the net_forward pass the handle holds; x and params as in that call; d_logp [n][n_actions], d_v [n] */
+int dbaz_trainer_net_backward(dbaz_trainer *t, const float *x, const float *d_logp, const float *d_v, const dbaz_net_tensors *params,
+                              const dbaz_net_tensors *grads, void *stream);
+
 /* ---- training-mode BatchNorm2d (+ ReLU) on NCHW tensors of any channel count: bn_input, bn0 and the heads' bn0
  * of ResNetZero under model.train(True) (nn.py:19-21,81-83,98-100,114; torch.nn.BatchNorm2d: batch statistics, biased variance,
  * running-stat update with momentum, gradient through the statistics).  Stateless: all pointers DEVICE memory, `workspace` of

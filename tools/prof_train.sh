@@ -27,5 +27,16 @@ if fwd and bwd:
     print("k_conv_t forward launches: avg %.1f us; input-gradient launches: avg %.1f us (with + g: %.1f, without: %.1f)"
           % (sum(fwd) / len(fwd), sum(bwd) / len(bwd), sum(bwd[1::2]) / len(bwd[1::2]), sum(bwd[0::2]) / len(bwd[0::2])))
 PY
+python3 - <<PY
+# the heads' GEMM launches in start order: per step fc forward, fc weight gradient, fc input gradient, head conv weight gradient(, stem)
+import csv
+rows = [r for r in csv.DictReader(open("$out/p_kernel_trace.csv")) if r["Kernel_Name"].startswith("k_gemm_f32")]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+steps = len([r for r in csv.DictReader(open("$out/p_kernel_trace.csv")) if r["Kernel_Name"].startswith("k_head_out_bwd")])
+if steps and d and len(d) % steps == 0:
+    per = len(d) // steps
+    print("k_gemm_f32 per step, in launch order (us):", ["%.1f" % (sum(d[i::per]) / steps) for i in range(per)])
+PY
 rm -f $out/p_kernel_trace.csv
 cat $out/step.json
