@@ -303,8 +303,9 @@ def single_tree_bench(args, local_rank, torch):
 
 
 def train_step_bench(args, local_rank):
-    """NeuralNetWrapper.train's step (nn.py:203-221) at the reference's batch size (configuration.py:61), residual
-    tower on the HIP kernels of csrc/train.hip against the same step with the tower on torch (MIOpen)."""
+    """NeuralNetWrapper.train's step (nn.py:203-221) at the reference's batch size (configuration.py:61), the whole
+    network, the loss and the SGD update on the HIP kernels of csrc/train.hip against the same step with the network on torch
+    (MIOpen / rocBLAS)."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import train_step_time as TS
     batch = 4096
@@ -316,7 +317,7 @@ def train_step_bench(args, local_rank):
     tf = flops / (hip["ms_per_step"] * 1e-3) / 1e12
     out = {"metric": "train_samples_per_sec", "value": hip["samples_per_sec"], "unit": "samples/s", "n_gpus": 1, "steps": args.train_step,
            "ms_per_step": hip["ms_per_step"], "higher_is_better": True, "vs_baseline": None,
-           "dtype": "f32 via f16x3 (hi,lo)-split MFMA (tower convs), f64 batch statistics; f32 torch for heads / loss / SGD",
+           "dtype": "f32 via f16x3 (hi,lo)-split MFMA (tower convs), exact f32 (stem, heads, loss, SGD), f64 batch statistics",
            "data": "synthetic", "config": {"workload": "%dx%d, ResNetZero %dx%d, batch %d, SGD momentum 0.9 wd 1e-4, batches from k_make_batch"
                                            % (args.board, args.board, args.blocks, args.channels, batch)},
            "torch_tower": {"ms_per_step": ref["ms_per_step"], "samples_per_sec": ref["samples_per_sec"]},
@@ -324,8 +325,8 @@ def train_step_bench(args, local_rank):
            "roofline": {"bound": "mfma", "kernel": "k_conv_t + k_wgrad_h3 (tower conv forward, input gradient, weight gradient), whole step in the time",
                         "achieved": tf, "peak": 2500.0 / 3, "unit": "TFLOP/s", "frac": tf / (2500.0 / 3), "flops_per_step": flops,
                         "traffic": None,
-                        "note": "the step moves ~32 GB of activations through HBM (4 ms at peak): the elementwise passes and the convs' "
-                                "un-overlapped load/store phases, not the MFMA pipe, set the time (DESIGN 5.5)"}}
+                        "note": "the step moves ~30 GB of activations through HBM (4 ms at peak): the elementwise passes and the convs' "
+                                "un-overlapped load/store phases, not the MFMA pipe, set the time (EXPERIMENTS.md 3)"}}
     print(json.dumps(out), flush=True)
 
 

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Times the optimizer step of the generation loop fed by the HIP batch kernel: ResNetZero 20x64, SGD momentum.  Residual
-tower forward/backward on csrc/train.hip (default) or on torch/MIOpen (--torch); AlphaZeroLoss and the SGD update are HIP
-kernels either way (dbaz_az_loss, dbaz_sgd_step); conv0 and the heads' convs / FCs are torch.  Prints one JSON line.
+tower forward/backward on csrc/train.hip (default) or on torch/MIOpen (--torch); bn_input, conv0 and both heads on csrc/train.hip as
+well (default: the whole network is two C calls) or on torch (--torch-heads); AlphaZeroLoss and the SGD update are HIP kernels either
+way (dbaz_az_loss, dbaz_sgd_step; --torch-loss / --torch-sgd).  Prints one JSON line.
 
-    python tools/train_step_time.py [batch] [--torch] [--steps K]      (bench.py --train-step prints both and a roofline)"""
+    python tools/train_step_time.py [batch] [--torch] [--torch-heads] [--steps K]   (bench.py --train-step prints both and a roofline)"""
 import json
 import os
 import sys
@@ -12,7 +13,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def measure(batch=4096, hip=True, steps=10, board=6, channels=64, blocks=20, device=0, hip_sgd=True, hip_loss=None):
+def measure(batch=4096, hip=True, steps=10, board=6, channels=64, blocks=20, device=0, hip_sgd=True, hip_loss=None, hip_heads=None):
     import torch
     from dotsboxesaz_amd import nn as dnn
     from dotsboxesaz_amd import train as T
@@ -50,7 +51,7 @@ def measure(batch=4096, hip=True, steps=10, board=6, channels=64, blocks=20, dev
                     break
                 t1 = time.perf_counter()
                 t_data += t1 - t0
-                p, v = T.training_forward(model, boards, hip_tower=hip)
+                p, v = T.training_forward(model, boards, hip_tower=hip, hip_heads=hip_heads)
                 t2 = time.perf_counter()
                 loss, parts = crit.tensors(p, v, pi, z, hip=hip_loss)  # as train.train(): the scalars are read one step late
                 loss.backward()
@@ -90,7 +91,9 @@ def measure(batch=4096, hip=True, steps=10, board=6, channels=64, blocks=20, dev
         buf = io.StringIO()
         pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(14)
         print(buf.getvalue(), file=sys.stderr)
-    out = {"what": "training step fed by k_make_batch; residual tower on %s, heads/loss/SGD on torch" % ("csrc/train.hip" if hip else "torch (MIOpen)"),
+    where = ("whole network on csrc/train.hip" if hip_heads is not False else "residual tower on csrc/train.hip, stem and heads on torch") if hip \
+        else "network on torch (MIOpen / rocBLAS)"
+    out = {"what": "training step fed by k_make_batch; %s; loss %s, SGD %s" % (where, "torch" if hip_loss is False else "HIP", "HIP" if hip_sgd else "torch"),
            "board": "%dx%d" % (board, board), "net": "ResNetZero %dx%d" % (blocks, channels), "batch": batch, "dataset_rows": len(ds),
            "steps": steps, "ms_per_step": 1e3 * dt / steps, "host_ms_fwd_bwd_opt_read": [round(x / steps, 3) for x in host_ms], "ms_data_per_step": 1e3 * td / steps, "samples_per_sec": batch * steps / dt}
     e.close()
@@ -102,4 +105,5 @@ if __name__ == "__main__":
     B = int(pos[0]) if pos else 4096
     K = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 10
     print(json.dumps(measure(B, "--torch" not in sys.argv, K, hip_sgd="--torch-sgd" not in sys.argv,
-                             hip_loss=False if "--torch-loss" in sys.argv else None)))
+                             hip_loss=False if "--torch-loss" in sys.argv else None,
+                             hip_heads=False if "--torch-heads" in sys.argv else None)))
