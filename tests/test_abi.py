@@ -34,6 +34,23 @@ def test_struct_sizes_match_header():
     # dbaz_config / dbaz_counters layouts as the C compiler sees them
     assert ctypes.sizeof(_lib.Config) == 232
     assert ctypes.sizeof(_lib.Counters) == 144
+    assert ctypes.sizeof(_lib.NetTensors) == 24 * 8 and ctypes.sizeof(_lib.NetRunning) == 10 * 8
+
+
+def test_struct_sizes_as_gcc_sees_the_header(tmp_path):
+    """include/dbaz.h compiled as plain C: sizeof of every struct that crosses the boundary equals the ctypes mirror's."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "dbaz.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", sizeof(dbaz_config), '
+                   'sizeof(dbaz_counters), sizeof(dbaz_net_tensors), sizeof(dbaz_net_running)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE, text=True).stdout.split()
+    assert [int(v) for v in out] == [ctypes.sizeof(_lib.Config), ctypes.sizeof(_lib.Counters), ctypes.sizeof(_lib.NetTensors),
+                                     ctypes.sizeof(_lib.NetRunning)]
 
 
 def test_create_without_gpu_fails_loudly():
