@@ -72,9 +72,6 @@ struct dbaz_trainer {
     dbaz_net_buffers *net = nullptr; // stem and heads (dbaz_trainer_net_forward), allocated on first use
 };
 
-#ifdef DBAZ_STAMP
-static int g_conv_delay_ticks = 0, g_conv_delay_group = 256; // diagnostic build: see k_conv_t
-#endif
 static thread_local std::string g_train_error; // message of a failed dbaz_trainer_create / dbaz_bn2d_* call; per thread
 
 static int terr(dbaz_trainer *t, int code, const char *fmt, ...)
@@ -230,7 +227,6 @@ struct ConvArgs {
     int n, S, H, W;
 #ifdef DBAZ_STAMP
     unsigned long long *stamp_out; // diagnostic build only: [grid][8 waves][8]
-    int delay_ticks, delay_group;  // experiment: workgroups with (blockIdx / delay_group) odd wait delay_ticks x 10 ns first
 #endif
 };
 
@@ -264,13 +260,6 @@ __global__ void __launch_bounds__(TT, 4) k_conv_t(ConvArgs a)
 #ifdef DBAZ_STAMP
     unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, tr0, tr1;
     TSTAMP_RT(tr0);
-    if (a.delay_ticks > 0 && ((blockIdx.x / a.delay_group) & 1)) { // experiment: the second workgroup of every CU starts late
-        unsigned long long now;
-        do {
-            __builtin_amdgcn_s_sleep(32);
-            TSTAMP_RT(now);
-        } while (now - tr0 < (unsigned long long)a.delay_ticks);
-    }
     TSTAMP(ts0);
 #endif
     const int R = ns * HW;
@@ -1195,7 +1184,6 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
 }
 
 #ifdef DBAZ_STAMP
-extern "C" void dbaz_debug_conv_delay(int ticks, int group) { g_conv_delay_ticks = ticks; g_conv_delay_group = group > 0 ? group : 256; }
 extern "C" int dbaz_debug_trainer_stamps(dbaz_trainer *t, unsigned long long *out, int n_wg)
 {
     if (!t || !out) return DBAZ_EINVAL;
@@ -1227,7 +1215,7 @@ static void tower_forward_rows(dbaz_trainer *t, int n, const float *const *conv_
         ca.bias = conv_b[l]; ca.add = nullptr; ca.out = t->Y + ae * l; ca.stat_part = t->part;
         ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
 #ifdef DBAZ_STAMP
-        ca.stamp_out = t->stamps; ca.delay_ticks = g_conv_delay_ticks; ca.delay_group = g_conv_delay_group;
+        ca.stamp_out = t->stamps;
 #endif
         hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         hipLaunchKernelGGL(k_bn_stats_fin, dim3(FIN_BLOCKS), dim3(TT), 0, s, t->part, grid, M, t->eps, t->momentum, t->mean + l * TC,
@@ -1290,7 +1278,7 @@ static int tower_backward_rows(dbaz_trainer *t, const float *const *bn_w, float 
         ca.add = (l & 1) ? nullptr : t->G; // the input of a block's first conv is also the block's skip input: + g of its end
         ca.n = n; ca.S = t->S; ca.H = t->H; ca.W = t->W;
 #ifdef DBAZ_STAMP
-        ca.stamp_out = t->stamps; ca.delay_ticks = g_conv_delay_ticks; ca.delay_group = g_conv_delay_group;
+        ca.stamp_out = t->stamps;
 #endif
         hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         if (t->wgrad_h3 && t->W == 7)

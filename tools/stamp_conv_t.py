@@ -16,10 +16,6 @@ dev = torch.device("cuda:0")
 m = dnn.ResNetZero(dnn.resnet_params(6, 6)).to(dev)
 m.train(True)
 x = torch.randn(n, 64, 7, 7, device=dev, requires_grad=True)
-L0 = _lib.load()
-if os.environ.get("CONV_DELAY"):   # experiment: every CU's second workgroup starts CONV_DELAY x 10 ns late
-    L0.dbaz_debug_conv_delay.argtypes = [C.c_int, C.c_int]
-    L0.dbaz_debug_conv_delay(int(os.environ["CONV_DELAY"]), int(os.environ.get("CONV_DELAY_GROUP", "256")))
 for _ in range(5):
     y = train_tower.resblocks_forward(m, x)
 torch.cuda.synchronize()
