@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall clock of the generation loop on one GPU (coach.learn_to_play, coach.py:124-161), replay resident in HBM: self-play
-(HIP) -> dataset + batches (HIP) -> optimizer steps (residual tower and batch norms on HIP, the rest torch) -> weights back
+(HIP) -> dataset + batches (HIP) -> optimizer steps (network, loss and SGD on HIP; torch holds the tensors) -> weights back
 into the engine.  6x6, ResNetZero 20x64, 800 sims/move.  Prints one JSON line.
 
     python tools/generation_loop.py [games per generation] [last generation] [file to copy the last checkpoint to]"""
