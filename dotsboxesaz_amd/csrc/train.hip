@@ -1952,7 +1952,7 @@ __global__ void __launch_bounds__(NET_WG) k_head_pack(const float *ph_cw, const 
 }
 
 // ---- head conv 1x1 (both heads): Yh[row][o] = bh[o] + sum_c A[row][c] Wh[c][o]; partial sums of Yh, Yh^2.  Thread = (row lane,
-// output quad), two rows per pass (each weight quad read from LDS serves both).
+// output quad), four rows per pass.
 __global__ void __launch_bounds__(NET_WG) k_head_conv(const f32x4 *__restrict__ a4, const float *__restrict__ Wh, const float *__restrict__ bh,
                                                       f32x4 *__restrict__ yh4, long long M, double *part)
 {
@@ -1962,29 +1962,30 @@ __global__ void __launch_bounds__(NET_WG) k_head_conv(const f32x4 *__restrict__ 
     const f32x4 bias = *reinterpret_cast<const f32x4 *>(bh + oq * 4);
     __syncthreads();
     double s[2][4] = {};
-    for (long long r0 = (long long)blockIdx.x * 64 + rl; r0 < M; r0 += (long long)gridDim.x * 64) {
-        const long long r1 = r0 + 32;
-        const bool two = r1 < M;
-        f32x4 acc0 = bias, acc1 = bias;
-#pragma unroll 4
+    constexpr int RP = 4; // rows per thread and pass: each weight quad read from LDS serves all of them
+    for (long long r0 = (long long)blockIdx.x * (32 * RP) + rl; r0 < M; r0 += (long long)gridDim.x * (32 * RP)) {
+        f32x4 acc[RP];
+#pragma unroll
+        for (int u = 0; u < RP; u++) acc[u] = bias;
+#pragma unroll 2
         for (int c4 = 0; c4 < TC / 4; c4++) {
-            const f32x4 x0 = a4[r0 * 16 + c4];
-            const f32x4 x1 = two ? a4[r1 * 16 + c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 x[RP];
+#pragma unroll
+            for (int u = 0; u < RP; u++) x[u] = r0 + 32 * u < M ? a4[(r0 + 32 * u) * 16 + c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const f32x4 w = *reinterpret_cast<const f32x4 *>(&wt[c4 * 4 + e][oq * 4]);
-                acc0 += x0[e] * w;
-                acc1 += x1[e] * w;
+#pragma unroll
+                for (int u = 0; u < RP; u++) acc[u] += x[u][e] * w;
             }
         }
-        yh4[r0 * 8 + oq] = acc0;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { const double d = acc0[e]; s[0][e] += d; s[1][e] += d * d; }
-        if (two) {
-            yh4[r1 * 8 + oq] = acc1;
+        for (int u = 0; u < RP; u++)
+            if (r0 + 32 * u < M) {
+                yh4[(r0 + 32 * u) * 8 + oq] = acc[u];
 #pragma unroll
-            for (int e = 0; e < 4; e++) { const double d = acc1[e]; s[0][e] += d; s[1][e] += d * d; }
-        }
+                for (int e = 0; e < 4; e++) { const double d = acc[u][e]; s[0][e] += d; s[1][e] += d * d; }
+            }
     }
     net_colsum_store<2, 8>(s, part);
 }
@@ -2311,18 +2312,17 @@ __global__ void __launch_bounds__(NET_WG) k_stem_fin1(const float *__restrict__ 
         Gsum[k * TC + o] = (float)v;
     }
 }
-// one workgroup: conv0's weight and bias gradients, bn_input's weight and bias gradients
+// conv0's weight and bias gradients, bn_input's weight and bias gradients
 __global__ void __launch_bounds__(NET_WG) k_stem_fin2(const float *__restrict__ Gsum, const float *__restrict__ w0, const float *in_w, const float *in_b,
                                                       const double *bias_part, int bias_nparts, float *g_w0, float *g_b0, float *g_in_w,
                                                       float *g_in_b)
 {
-    __shared__ double rg[NET_WG], rb[NET_WG];
+    // grid of 5: workgroups 0..2 = bn_input's gradient for input channel ci, 3 = conv0's weight gradient, 4 = its bias gradient
+    // (one workgroup doing the five in turn was five global round trips behind each other: 23 us)
+    __shared__ double rg[NET_WG], rb[NET_WG / 64];
     const int tid = threadIdx.x;
-    for (int i = tid; i < TC * 27; i += NET_WG) {
-        const int o = i / 27, k = i - o * 27, ci = k / 9, t = k - ci * 9;
-        g_w0[i] = in_w[ci] * Gsum[(ci * 9 + t) * TC + o] + in_b[ci] * Gsum[(27 + t) * TC + o];
-    }
-    for (int ci = 0; ci < 3; ci++) {
+    if (blockIdx.x < 3) {
+        const int ci = blockIdx.x;
         double a = 0.0, b = 0.0;
         for (int i = tid; i < TC * 9; i += NET_WG) {
             const int o = i / 9, t = i - o * 9;
@@ -2332,22 +2332,25 @@ __global__ void __launch_bounds__(NET_WG) k_stem_fin2(const float *__restrict__ 
         }
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) { a += __shfl_xor(a, sh); b += __shfl_xor(b, sh); }
-        __syncthreads();
         if ((tid & 63) == 0) { rg[tid >> 6] = a; rb[tid >> 6] = b; }
         __syncthreads();
         if (tid == 0) {
             g_in_w[ci] = (float)((rg[0] + rg[1]) + (rg[2] + rg[3]));
             g_in_b[ci] = (float)((rb[0] + rb[1]) + (rb[2] + rb[3]));
         }
-    }
-    {
-        const int c = tid & 63, j = tid >> 6;
+    } else if (blockIdx.x == 3) {
+        for (int i = tid; i < TC * 27; i += NET_WG) {
+            const int o = i / 27, k = i - o * 27, ci = k / 9, t = k - ci * 9;
+            g_w0[i] = in_w[ci] * Gsum[(ci * 9 + t) * TC + o] + in_b[ci] * Gsum[(27 + t) * TC + o];
+        }
+    } else {
+        const int c = tid & 63, jj = tid >> 6;
         double t = 0.0;
-        for (int b = j; b < bias_nparts; b += NET_WG / 64) t += bias_part[(size_t)b * TC + c];
-        __syncthreads();
+#pragma unroll 8
+        for (int b = jj; b < bias_nparts; b += NET_WG / 64) t += bias_part[(size_t)b * TC + c];
         rg[tid] = t;
         __syncthreads();
-        if (j == 0) g_b0[c] = (float)((rg[c] + rg[64 + c]) + (rg[128 + c] + rg[192 + c]));
+        if (jj == 0) g_b0[c] = (float)((rg[c] + rg[64 + c]) + (rg[128 + c] + rg[192 + c]));
     }
 }
 
@@ -2460,7 +2463,7 @@ extern "C" int dbaz_trainer_net_forward(dbaz_trainer *t, int32_t n, const float 
     // heads
     hipLaunchKernelGGL(k_head_pack, dim3(256), dim3(NET_WG), 0, s, P->ph_conv_w, P->ph_conv_b, P->vh_conv_w, P->vh_conv_b, P->ph_fc_w, P->ph_fc_b,
                        P->vh_fc0_w, P->vh_fc0_b, st + ST_WH, st + ST_BH, b->Wc, b->bc, HW, A, VF, NOp);
-    const int hb = (int)std::min<long long>(NET_HB, (M + 63) / 64);
+    const int hb = (int)std::min<long long>(NET_HB, (M + 127) / 128);
     hipLaunchKernelGGL(k_head_conv, dim3(hb), dim3(NET_WG), 0, s, reinterpret_cast<const f32x4 *>(t->A + ae * L), st + ST_WH, st + ST_BH,
                        reinterpret_cast<f32x4 *>(b->Yh), M, b->ws + WS_HP1);
     hipLaunchKernelGGL(k_head_stats_fin, dim3(HC2), dim3(NET_WG), 0, s, b->ws + WS_HP1, hb, M, t->eps, t->momentum, st + ST_MEAN_H, st + ST_INVSTD_H,
@@ -2529,7 +2532,7 @@ extern "C" int dbaz_trainer_net_backward(dbaz_trainer *t, const float *x, const 
     const int ssplits = (int)std::min<long long>(STEM_SPLITS, (M + 31) / 32);
     launch_gemm(s, b->val, 1, 36, t->dY, TC, 1, b->stem_part, TC, 36, TC, (int)M, nullptr, ssplits, (long long)36 * TC);
     hipLaunchKernelGGL(k_stem_fin1, dim3(36 * 4), dim3(NET_WG), 0, s, b->stem_part, gemm_splits((int)M, ssplits), b->Gsum);
-    hipLaunchKernelGGL(k_stem_fin2, dim3(1), dim3(NET_WG), 0, s, b->Gsum, P->conv0_w, P->bn_input_w, P->bn_input_b, t->part, rb, G->conv0_w, G->conv0_b,
+    hipLaunchKernelGGL(k_stem_fin2, dim3(5), dim3(NET_WG), 0, s, b->Gsum, P->conv0_w, P->bn_input_w, P->bn_input_b, t->part, rb, G->conv0_w, G->conv0_b,
                        G->bn_input_w, G->bn_input_b);
     HIPCHK(t, hipGetLastError());
     t->have_fwd = false;

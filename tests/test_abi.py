@@ -69,3 +69,25 @@ def test_bad_config_rejected_before_touching_the_device():
         Engine(12, 12, 4)  # A = 338 > 256
     with pytest.raises(_lib.DbazError):
         Engine(3, 3, 0)
+
+
+def _header_struct_fields(name):
+    src = open(os.path.join(REPO, "include", "dbaz.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        for part in decl.split(","):
+            m = re.search(r"([a-z0-9_]+)\s*$", part.strip())
+            if m and part.strip():
+                fields.append(m.group(1))
+    return fields
+
+
+def test_net_structs_field_order_matches_header():
+    """dbaz_net_tensors / dbaz_net_running are structs of pointers: the ctypes mirrors must list them in the header's order."""
+    assert _header_struct_fields("dbaz_net_tensors") == [f for f, _ in _lib.NetTensors._fields_]
+    assert _header_struct_fields("dbaz_net_running") == [f for f, _ in _lib.NetRunning._fields_]
+    from dotsboxesaz_amd import train_tower
+    assert list(train_tower._NET_SINGLE) + list(train_tower._NET_BLOCK) == sorted(
+        [f for f, _ in _lib.NetTensors._fields_], key=lambda f: (f.startswith("blk_"), [g for g, _ in _lib.NetTensors._fields_].index(f)))
