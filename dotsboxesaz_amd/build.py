@@ -23,6 +23,7 @@ UNITS = [
     ("nn.hip", []),
     ("replay.hip", ["-ffp-contract=off"]),  # Kahan-compensated float64 means (pandas group_mean)
     ("train.hip", []),
+    ("train_net.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -233,7 +233,7 @@ def batch_norm_train(bn, x, relu=False):
     return _BNFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
 
 
-# ---- the whole network of the optimizer step on csrc/train.hip: p, v = model(boards) (nn.py:108-122) and its backward
+# ---- the whole network of the optimizer step on csrc/train_net.hip + csrc/train.hip: p, v = model(boards) (nn.py:108-122) and its backward
 _NET_SINGLE = ("bn_input_w", "bn_input_b", "conv0_w", "conv0_b", "bn0_w", "bn0_b", "ph_conv_w", "ph_conv_b", "ph_bn_w", "ph_bn_b", "ph_fc_w",
                "ph_fc_b", "vh_conv_w", "vh_conv_b", "vh_bn_w", "vh_bn_b", "vh_fc0_w", "vh_fc0_b", "vh_fc1_w", "vh_fc1_b")
 _NET_BLOCK = ("blk_conv_w", "blk_conv_b", "blk_bn_w", "blk_bn_b")

@@ -1,4 +1,4 @@
-"""The whole network of the optimizer step on HIP (csrc/train.hip, dbaz_trainer_net_forward / _backward: bn_input, conv0 + bn0, the
+"""The whole network of the optimizer step on HIP (csrc/train_net.hip + csrc/train.hip, dbaz_trainer_net_forward / _backward: bn_input, conv0 + bn0, the
 residual tower, both heads) against torch autograd.
 
 Ground truth = `train.training_forward(..., hip_tower=False)` -- the reference's operation order (nn.py:108-122) composed of torch
