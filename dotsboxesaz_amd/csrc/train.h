@@ -33,7 +33,7 @@ struct dbaz_trainer {
     int dev = 0, H = 0, W = 0, HW = 0, L = 0, maxN = 0, n = 0;
     int S = 1, Sw = 1, cus = 256;
 #ifdef DBAZ_STAMP
-    unsigned long long *stamps = nullptr; // diagnostic build only
+    unsigned long long *stamps = nullptr, *stamps_wg = nullptr; // diagnostic build only (k_conv_t, k_wgrad_h3)
 #endif
     float eps = 1e-5f, momentum = 0.1f;
     size_t conv_lds = 0, wgrad_lds = 0;

@@ -824,9 +824,18 @@ __device__ __forceinline__ s4v tr_read(unsigned a) { return __builtin_amdgcn_ds_
 
 template <int PWC> // W + 1 at compile time (tap offsets become immediates of the reads), 0 = any board
 __global__ void __launch_bounds__(TT, 2) k_wgrad_h3(const float *__restrict__ act, const float *__restrict__ dy, const unsigned *act_max,
-                                                    const unsigned *dy_max, int n, int Sw, int H, int W, float *__restrict__ part)
+                                                    const unsigned *dy_max, int n, int Sw, int H, int W, float *__restrict__ part
+#ifdef DBAZ_STAMP
+                                                    , unsigned long long *stamp_out
+#endif
+)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef DBAZ_STAMP
+    unsigned long long ws0, ws1, wsa, wsb, wsc, ws_commit = 0, ws_loop = 0, wr0, wr1;
+    TSTAMP_RT(wr0);
+    TSTAMP(ws0);
+#endif
     const int HW = H * W;
     const WhGeo geo = wh_geo(Sw, H, W);
     const int PW = PWC ? PWC : geo.PW, NK = geo.NK;
@@ -840,14 +849,6 @@ __global__ void __launch_bounds__(TT, 2) k_wgrad_h3(const float *__restrict__ ac
     f32x4 acc[9][2];
 #pragma unroll
     for (int t = 0; t < 9; t++) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    for (int i = tid; i < (geo.RA + geo.RK) * (WH_SB / 16); i += TT) reinterpret_cast<f32x4 *>(Ai)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int per_s = H * PW; // dY rows per sample
-    for (int j = tid; j < geo.RK; j += TT) tabA[j] = j < Sw * per_s ? (j + (j / per_s) * PW) * WH_SB : 0;
-    for (int r = tid; r < Sw * HW; r += TT) {
-        const int sidx = r / HW, pos = r - sidx * HW, y = pos / W, x = pos - y * W;
-        const int j = sidx * per_s + y * PW + x;
-        rowmap[r] = j | ((geo.G + sidx * (H + 1) * PW + y * PW + x) << 16);
-    }
     const float sA = scale_from_max(*act_max), sD = scale_from_max(*dy_max);
     const int nchunks = (n + Sw - 1) / Sw;
     f32x4 pf[WG_MAXLD];
@@ -888,8 +889,18 @@ __global__ void __launch_bounds__(TT, 2) k_wgrad_h3(const float *__restrict__ ac
             }
         }
     };
-    __syncthreads(); // tables, zeroed images
+    // the first chunk's rows are requested BEFORE the images are zeroed and the tables built (2 us of HBM latency that used to
+    // follow them: the prologue was 9 % of the workgroup)
     if ((int)blockIdx.x < nchunks) issue(blockIdx.x, 0);
+    for (int i = tid; i < (geo.RA + geo.RK) * (WH_SB / 16); i += TT) reinterpret_cast<f32x4 *>(Ai)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int per_s = H * PW; // dY rows per sample
+    for (int j = tid; j < geo.RK; j += TT) tabA[j] = j < Sw * per_s ? (j + (j / per_s) * PW) * WH_SB : 0;
+    for (int r = tid; r < Sw * HW; r += TT) {
+        const int sidx = r / HW, pos = r - sidx * HW, y = pos / W, x = pos - y * W;
+        const int j = sidx * per_s + y * PW + x;
+        rowmap[r] = j | ((geo.G + sidx * (H + 1) * PW + y * PW + x) << 16);
+    }
+    __syncthreads(); // tables, zeroed images
     int toff[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) toff[t] = ((t / 3) * PW + (t % 3)) * WH_SB;
@@ -898,12 +909,15 @@ __global__ void __launch_bounds__(TT, 2) k_wgrad_h3(const float *__restrict__ ac
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)Ai; // 32-bit LDS addresses from here on
     const unsigned abase = lds0 + cit * 32 + lcol;
     const unsigned dbase = lds0 + (unsigned)geo.RA * WH_SB + lrow * WH_SB + ch * 64 + lcol;
+    TSTAMP(ws1);
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         int tz = 0;
         asm volatile("" : "+v"(tz));
+        TSTAMP(wsa);
         __syncthreads(); // the previous chunk's reads are done
         commit(tz);
         __syncthreads();
+        TSTAMP(wsb);
         asm volatile("" : "+v"(tz));
         if (chunk + (int)gridDim.x < nchunks) issue(chunk + gridDim.x, tz);
         FragH ah[3], al[3];        // A fragments of three consecutive taps
@@ -946,7 +960,15 @@ __global__ void __launch_bounds__(TT, 2) k_wgrad_h3(const float *__restrict__ ac
             }
             tA0 = nA0; tA1 = nA1;
         }
+#ifdef DBAZ_STAMP
+        TSTAMP(wsc);
+        ws_commit += wsb - wsa;
+        ws_loop += wsc - wsb;
+#endif
     }
+#ifdef DBAZ_STAMP
+    TSTAMP(wsa);
+#endif
     // lane holds dW[tap][cin = cit*16 + 4 gq + i][cout = (2 ch + j)*16 + m16], scaled by sA * sD
     const float inv = 1.0f / (sA * sD);
     float *o = part + (size_t)blockIdx.x * 9 * TC * TC;
@@ -957,6 +979,15 @@ __global__ void __launch_bounds__(TT, 2) k_wgrad_h3(const float *__restrict__ ac
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 o[((size_t)tap * TC + cit * 16 + 4 * gq + i) * TC + (2 * ch + j) * 16 + m16] = acc[tap][j][i] * inv;
+#ifdef DBAZ_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSTAMP(wsb);
+    TSTAMP_RT(wr1);
+    if (stamp_out && lane == 0) {
+        unsigned long long *so = stamp_out + ((size_t)blockIdx.x * 8 + wave) * 8;
+        so[0] = ws1 - ws0; so[1] = ws_commit; so[2] = ws_loop; so[3] = wsb - wsa; so[4] = wsb - ws0; so[5] = wr0; so[6] = wr1; so[7] = 0;
+    }
+#endif
 }
 
 // sums the workgroups' partial gradients (f64) and writes torch's [cout][cin][3][3]: 64 outputs x 4 partial lanes per block
@@ -1094,6 +1125,7 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
     alloc((void **)&t->relu_mask, (size_t)t->L * t->maxN * t->HW * 8);
 #ifdef DBAZ_STAMP
     alloc((void **)&t->stamps, (size_t)(t->maxN / t->S + 1) * 64 * 8);
+    alloc((void **)&t->stamps_wg, (size_t)(t->cus + 1) * 64 * 8);
 #endif
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_conv_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->conv_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->wgrad_lds);
@@ -1109,6 +1141,12 @@ extern "C" int dbaz_trainer_create(int32_t rows, int32_t cols, int32_t channels,
 }
 
 #ifdef DBAZ_STAMP
+extern "C" int dbaz_debug_trainer_wgrad_stamps(dbaz_trainer *t, unsigned long long *out, int n_wg)
+{
+    if (!t || !out) return DBAZ_EINVAL;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, t->stamps_wg, (size_t)std::min(n_wg, t->cus) * 64 * 8, hipMemcpyDeviceToHost) == hipSuccess ? DBAZ_OK : DBAZ_ESTATE;
+}
 extern "C" int dbaz_debug_trainer_stamps(dbaz_trainer *t, unsigned long long *out, int n_wg)
 {
     if (!t || !out) return DBAZ_EINVAL;
@@ -1206,10 +1244,18 @@ int tower_backward_rows(dbaz_trainer *t, const float *const *bn_w, float *const 
         hipLaunchKernelGGL(k_conv_t, dim3(grid), dim3(TT), t->conv_lds, s, ca);
         if (t->wgrad_h3 && t->W == 7)
             hipLaunchKernelGGL((k_wgrad_h3<8>), dim3(wg), dim3(TT), t->wgrad_h3_lds, s, t->A + ae * l, t->dY, t->amax + l, dymax, n, Sw, t->H,
-                               t->W, t->wg_part);
+                               t->W, t->wg_part
+#ifdef DBAZ_STAMP
+                               , t->stamps_wg
+#endif
+                               );
         else if (t->wgrad_h3)
             hipLaunchKernelGGL((k_wgrad_h3<0>), dim3(wg), dim3(TT), t->wgrad_h3_lds, s, t->A + ae * l, t->dY, t->amax + l, dymax, n, Sw, t->H,
-                               t->W, t->wg_part);
+                               t->W, t->wg_part
+#ifdef DBAZ_STAMP
+                               , t->stamps_wg
+#endif
+                               );
         else
             hipLaunchKernelGGL(k_wgrad, dim3(wg), dim3(TT), t->wgrad_lds, s, t->A + ae * l, t->dY, n, Sw, t->H, t->W, t->wg_part);
         // weight gradient totals + conv bias gradient + (last C workgroups) the BatchNorm-backward totals of the layer below
