@@ -7,7 +7,7 @@ with the HDF file between the stages replaced by packed replay rows that never l
                   when torch.distributed is initialised) and enter the ReplayStore with the
                   train/validation flags of coach.py:59-63
     train_nn(g)   window rule of coach.py:148-149, HDFStoreDataset semantics on the device
-                  (train_data.ReplayDataset), optimizer step in torch on ROCm (train.train)
+                  (train_data.ReplayDataset), optimizer step on csrc/train.hip + train_net.hip behind torch autograd (train.train)
     compute_elo   two-model match play on the device (self_play.compute_elo)
 
 This is the thin caller of the hot path, not a port of the reference's control plane: no HDF, no

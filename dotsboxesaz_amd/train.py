@@ -3,12 +3,15 @@
 (nn.py:292-313) and `GenerationLrScheduler` (nn.py:276-289).
 
 What runs where: the DATA side (dataset build from replay rows in HBM, batch gather, symmetries) is
-hand-written HIP (`train_data.py` -> csrc/replay.hip).  The residual blocks of a 64-channel ResNetZero
--- 98 % of the step's FLOPs -- run forward and backward in hand-written HIP as well when the model is in
-training mode on the GPU (`train_tower.py` -> csrc/train.hip; `hip_tower=False` keeps them on torch).
-The rest of this file's arithmetic (bn_input, conv0, the heads, the loss, SGD) is torch on ROCm --
+hand-written HIP (`train_data.py` -> csrc/replay.hip).  The NETWORK of a shipped-shape ResNetZero (3 input
+planes, 64 channels, 16 head channels) in training mode on the GPU runs forward and backward in hand-written
+HIP as well: stem, residual tower and both heads are two C calls (`train_tower.network_forward` ->
+csrc/train_net.hip + csrc/train.hip); other head shapes keep the tower in HIP and the stem / heads on torch
+(`hip_heads=False` forces that, `hip_tower=False` the whole network on torch -- the CPU goldens' path).
+`AlphaZeroLoss` and the SGD update are HIP kernels too (`dbaz_az_loss`, `dbaz_sgd_step`).  torch owns the
+parameter / gradient tensors, the autograd graph around those calls, checkpoints and the LR schedule --
 plumbing around the product, never on the self-play path: the weight containers of `nn.py` still refuse
-`forward()`; `training_forward` composes their sub-modules explicitly for autograd.
+`forward()`; `training_forward` composes their sub-modules explicitly where torch evaluates them.
 """
 import os
 
