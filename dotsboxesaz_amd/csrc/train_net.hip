@@ -767,7 +767,7 @@ extern "C" int dbaz_trainer_net_forward(dbaz_trainer *t, int32_t n, const float 
     if (n < 1 || n > t->maxN) return terr(t, DBAZ_EINVAL, "batch %d outside 1..%d", n, t->maxN);
     if (!x || !logp || !v || !net_tensors_ok(P)) return terr(t, DBAZ_EINVAL, "null argument");
     if (head_channels != HC) return terr(t, DBAZ_EINVAL, "the heads are built for %d channels (got %d)", HC, head_channels);
-    if (n_actions < 1 || n_actions > 4096 || value_fc < 1 || value_fc > 256)
+    if (n_actions < 1 || n_actions > 1024 || value_fc < 1 || value_fc > 256) // (k_head_out_bwd's column sums: 4 (A + 2 vf + 1) doubles of LDS)
         return terr(t, DBAZ_EINVAL, "n_actions %d / value_fc %d unsupported", n_actions, value_fc);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(t, hipSetDevice(t->dev));

@@ -325,7 +325,7 @@ def net_supported(model, x):
             and tuple(c0.dilation) == (1, 1) and c0.groups == 1 and c0.bias is not None and bn_in.num_features == 3)
     fcs = (ph.fc.in_features == 16 * H * W and vh.fc0.in_features == 16 * H * W and vh.fc1.in_features == vh.fc0.out_features
            and vh.fc1.out_features == 1 and ph.fc.bias is not None and vh.fc0.bias is not None and vh.fc1.bias is not None
-           and ph.fc.out_features <= 4096 and vh.fc0.out_features <= 256)
+           and ph.fc.out_features <= 1024 and vh.fc0.out_features <= 256)
     return bool(stem and conv1x1(ph.conv0) and conv1x1(vh.conv0) and fcs and all(_bn_ok(b) for b in (bn_in, r.bn0, ph.bn0, vh.bn0)))
 
 
