@@ -16,6 +16,18 @@ def _temperature_items(temperature):
     return items
 
 
+def _dense_from_grouped(w, channels):
+    """Conv2d(groups=g) weight [C][C/g][kh][kw] (the reference's n_groups, nn.py:61-71) -> the dense [C][C][kh][kw] weight of the
+    same function: output group i sees input group i only, every other product is an exact zero."""
+    cpg = w.shape[1]
+    if channels % cpg:
+        raise ValueError("grouped conv weight %s does not divide %d channels" % (w.shape, channels))
+    dense = np.zeros((channels, channels) + w.shape[2:], np.float32)
+    for g in range(channels // cpg):
+        dense[g * cpg:(g + 1) * cpg, g * cpg:(g + 1) * cpg] = w[g * cpg:(g + 1) * cpg]
+    return dense
+
+
 class Engine:
     """Self-play rollout engine on one MI355X.
 
@@ -154,6 +166,9 @@ class Engine:
                 continue
             a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
             a = np.ascontiguousarray(a, np.float32)
+            if kind == "resnet" and ".resblocks." in k and k.endswith(".weight") and a.ndim == 4 and a.shape[0] == channels \
+                    and a.shape[1] < channels:
+                a = _dense_from_grouped(a, channels)
             self._ck(self._L.dbaz_nn_set_tensor(self.h, k.encode(), _p(a), a.size))
         self._ck(self._L.dbaz_nn_commit(self.h))
 

@@ -16,11 +16,11 @@ def _get(d, k):
 
 
 class _ResBlock(nn.Module):
-    def __init__(self, ch, k):
+    def __init__(self, ch, k, n_groups=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(ch, ch, k, padding=(k - 1) // 2)
+        self.conv1 = nn.Conv2d(ch, ch, k, padding=(k - 1) // 2, groups=n_groups)
         self.bn1 = nn.BatchNorm2d(ch)
-        self.conv2 = nn.Conv2d(ch, ch, k, padding=(k - 1) // 2)
+        self.conv2 = nn.Conv2d(ch, ch, k, padding=(k - 1) // 2, groups=n_groups)
         self.bn2 = nn.BatchNorm2d(ch)
 
 
@@ -28,12 +28,15 @@ class _ResNet(nn.Module):
     def __init__(self, in_channels, nb_channels, kernel_size, nb_blocks, n_groups=1, inner_channels=None,
                  pad_layer0=True):
         super().__init__()
-        if kernel_size != 3 or n_groups != 1 or inner_channels or not pad_layer0:
-            raise NotImplementedError("the HIP tower implements the shipped configuration: 3x3 kernels, "
-                                      "no groups, no inner conv (configuration.py:134-142)")
+        if kernel_size != 3 or inner_channels or not pad_layer0 or n_groups < 1 or nb_channels % n_groups:
+            raise NotImplementedError("the HIP tower implements 3x3 kernels with a padded first layer and no inner conv "
+                                      "(configuration.py:134-142); n_groups must divide nb_channels")
+        # n_groups > 1 (nn.py:33-47,61-71): the grouped weights [ch][ch / groups][3][3] are expanded to the dense block-diagonal
+        # form when they are loaded into the engine (Engine.load_state_dict) -- same sums, the off-diagonal products are exact zeros
+        self.n_groups = n_groups
         self.conv0 = nn.Conv2d(in_channels, nb_channels, 3, padding=1)
         self.bn0 = nn.BatchNorm2d(nb_channels)
-        self.resblocks = nn.Sequential(*[_ResBlock(nb_channels, kernel_size) for _ in range(nb_blocks)])
+        self.resblocks = nn.Sequential(*[_ResBlock(nb_channels, kernel_size, n_groups) for _ in range(nb_blocks)])
 
 
 class _PolicyHead(nn.Module):
@@ -113,12 +116,12 @@ class SimpleNN(nn.Module):
         self.load_state_dict(torch.load(fn, map_location="cpu", weights_only=True)["model_dict"])
 
 
-def resnet_params(rows, cols, channels=64, blocks=20, head_channels=16, value_fc=8):
+def resnet_params(rows, cols, channels=64, blocks=20, head_channels=16, value_fc=8, n_groups=1):
     """The shipped `resnet` configuration (configuration.py:134-156) resized to a rows x cols board."""
     H, W = rows + 1, cols + 1
     return {"nn": {"model_parameters": {
         "resnet": {"pad_layer0": True, "in_channels": 3, "nb_channels": channels, "inner_channels": None,
-                   "kernel_size": 3, "nb_blocks": blocks, "n_groups": 1},
+                   "kernel_size": 3, "nb_blocks": blocks, "n_groups": n_groups},
         "policy_head": {"in_channels": channels, "inner_channels": head_channels, "fc_in": head_channels * H * W,
                         "nb_actions": 2 * H * W},
         "value_head": {"in_channels": channels, "inner_channels": head_channels, "fc_in": head_channels * H * W,

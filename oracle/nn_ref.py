@@ -15,16 +15,17 @@ from torch import nn
 import torch.nn.functional as F
 
 
-def _conv(cin, cout, k, pad=True):
-    return nn.Conv2d(cin, cout, k, padding=(k - 1) // 2 if pad else 0)
+def _conv(cin, cout, k, pad=True, groups=1):
+    # nn.py:61-71 (_create_conv_layer, odd kernels): groups = n_groups
+    return nn.Conv2d(cin, cout, k, padding=(k - 1) // 2 if pad else 0, groups=groups)
 
 
 class _Block(nn.Module):
-    def __init__(self, ch, k):
+    def __init__(self, ch, k, groups=1):
         super().__init__()
-        self.conv1 = _conv(ch, ch, k)
+        self.conv1 = _conv(ch, ch, k, groups=groups)
         self.bn1 = nn.BatchNorm2d(ch)
-        self.conv2 = _conv(ch, ch, k)
+        self.conv2 = _conv(ch, ch, k, groups=groups)
         self.bn2 = nn.BatchNorm2d(ch)
 
     def forward(self, x):
@@ -35,11 +36,11 @@ class _Block(nn.Module):
 
 
 class _Tower(nn.Module):
-    def __init__(self, cin, ch, k, nb):
+    def __init__(self, cin, ch, k, nb, groups=1):
         super().__init__()
-        self.conv0 = _conv(cin, ch, 3)
+        self.conv0 = _conv(cin, ch, 3)  # (nn.py:17: the first conv is never grouped)
         self.bn0 = nn.BatchNorm2d(ch)
-        self.resblocks = nn.Sequential(*[_Block(ch, k) for _ in range(nb)])
+        self.resblocks = nn.Sequential(*[_Block(ch, k, groups) for _ in range(nb)])
 
     def forward(self, x):
         return self.resblocks(F.relu(self.bn0(self.conv0(x))))
@@ -77,13 +78,13 @@ class ResNetZeroRef(nn.Module):
     same random init."""
 
     def __init__(self, rows, cols, channels=64, blocks=20, kernel=3, head_channels=16, value_fc=8,
-                 in_channels=3):
+                 in_channels=3, n_groups=1):
         super().__init__()
         H, W = rows + 1, cols + 1
         self.cfg = dict(rows=rows, cols=cols, channels=channels, blocks=blocks, kernel=kernel,
-                        head_channels=head_channels, value_fc=value_fc, in_channels=in_channels)
+                        head_channels=head_channels, value_fc=value_fc, in_channels=in_channels, n_groups=n_groups)
         self.bn_input = nn.BatchNorm2d(in_channels)
-        self.resnet = _Tower(in_channels, channels, kernel, blocks)
+        self.resnet = _Tower(in_channels, channels, kernel, blocks, n_groups)
         self.value_head = _ValueHead(channels, head_channels, head_channels * H * W, value_fc)
         self.policy_head = _PolicyHead(channels, head_channels, head_channels * H * W, 2 * H * W)
 

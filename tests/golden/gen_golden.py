@@ -378,12 +378,12 @@ def gen_pending():
     print("pending.npz", len(cases), "cases")
 
 
-def ref_resnet_params(rows, cols, channels, blocks, head_ch, value_fc):
+def ref_resnet_params(rows, cols, channels, blocks, head_ch, value_fc, n_groups=1):
     from utils.utils import DotDict
     H, W = rows + 1, cols + 1
     return DotDict({"nn": {"model_parameters": {
         "resnet": {"pad_layer0": True, "in_channels": 3, "nb_channels": channels, "inner_channels": None,
-                   "kernel_size": 3, "nb_blocks": blocks, "n_groups": 1},
+                   "kernel_size": 3, "nb_blocks": blocks, "n_groups": n_groups},
         "policy_head": {"in_channels": channels, "inner_channels": head_ch, "fc_in": head_ch * H * W,
                         "nb_actions": 2 * H * W},
         "value_head": {"in_channels": channels, "inner_channels": head_ch, "fc_in": head_ch * H * W,
@@ -421,6 +421,21 @@ def gen_nn():
         X = sample_features(r, c, 12, 5)
         p, v = wrapper.predict_sync(X)
         out[tag + "_cfg"] = np.array([r, c, ch, nb, hc, vf], dtype=np.int32)
+        out[tag + "_X"] = X
+        out[tag + "_p"] = p
+        out[tag + "_v"] = v
+        for k, t in model.state_dict().items():
+            out[tag + "_w_" + k] = t.numpy()
+    # (a') the reference's n_groups option (nn.py:33-47,61-71): grouped 3x3 convs in the blocks, committed weights
+    for (r, c, ch, nb, hc, vf, ng, tag) in ((3, 3, 16, 2, 4, 8, 2, "groups33"), (2, 3, 16, 1, 4, 4, 4, "groups23")):
+        torch.manual_seed(13)
+        params = ref_resnet_params(r, c, ch, nb, hc, vf, ng)
+        model = ref_nn.ResNetZero(params)
+        nn_ref.randomize_bn(model, 17)
+        wrapper = ref_nn.NeuralNetWrapper(model, params)
+        X = sample_features(r, c, 12, 6)
+        p, v = wrapper.predict_sync(X)
+        out[tag + "_cfg"] = np.array([r, c, ch, nb, hc, vf, ng], dtype=np.int32)
         out[tag + "_X"] = X
         out[tag + "_p"] = p
         out[tag + "_v"] = v

@@ -22,11 +22,14 @@ def engine_for(rows, cols, model, n_slots=64, precision=0):
 # precision 0 = exact f32 MFMA; 1 = f16x3, the mode bench.py times and the drop-in entry points default to: BOTH are compared with
 # the reference's own (p, v) (NeuralNetWrapper.predict_sync, nn.py:155-160, recorded in tests/golden/nn.npz)
 @pytest.mark.parametrize("precision", [0, 1])
-@pytest.mark.parametrize("tag", ["small33", "small66", "small23"])
+@pytest.mark.parametrize("tag", ["small33", "small66", "small23", "groups33", "groups23"])
 def test_golden_committed_weights(golden_nn, tag, precision):
+    """groups33 / groups23: networks with the reference's n_groups option (grouped convs, nn.py:33-47,61-71); the engine expands
+    their [C][C/g][3][3] weights to the dense block-diagonal form when they are loaded."""
     g = golden_nn
-    r, c, ch, nb, hc, vf = [int(x) for x in g[tag + "_cfg"]]
-    m = nn_ref.ResNetZeroRef(r, c, ch, nb, 3, hc, vf)
+    cfg = [int(x) for x in g[tag + "_cfg"]]
+    r, c, ch, nb, hc, vf = cfg[:6]
+    m = nn_ref.ResNetZeroRef(r, c, ch, nb, 3, hc, vf, n_groups=cfg[6] if len(cfg) > 6 else 1)
     m.load_state_dict({k[len(tag) + 3:]: torch.tensor(g[k]) for k in g.files if k.startswith(tag + "_w_")})
     e = engine_for(r, c, m, precision=precision)
     assert e.cfg.nn_precision == precision

@@ -10,14 +10,16 @@ TOL = 1e-4  # north-star tolerance for policy/value (fp32)
 
 
 def _small(g, tag):
-    r, c, ch, nb, hc, vf = [int(x) for x in g[tag + "_cfg"]]
-    m = nn_ref.ResNetZeroRef(r, c, ch, nb, 3, hc, vf)
+    cfg = [int(x) for x in g[tag + "_cfg"]]
+    r, c, ch, nb, hc, vf = cfg[:6]
+    m = nn_ref.ResNetZeroRef(r, c, ch, nb, 3, hc, vf, n_groups=cfg[6] if len(cfg) > 6 else 1)
     sd = {k[len(tag) + 3:]: torch.tensor(g[k]) for k in g.files if k.startswith(tag + "_w_")}
     m.load_state_dict(sd, strict=True)  # reference key names load unchanged
     return m
 
 
-@pytest.mark.parametrize("tag", ["small33", "small66", "small23"])
+# groups33 / groups23: the reference's n_groups option (grouped 3x3 convs in the blocks, nn.py:33-47,61-71)
+@pytest.mark.parametrize("tag", ["small33", "small66", "small23", "groups33", "groups23"])
 def test_committed_weights(golden_nn, tag):
     g = golden_nn
     torch.set_num_threads(1)
@@ -96,3 +98,23 @@ def test_restated_blocks_in_training_mode_match_reference_goldens():
         for k, v in blocks.state_dict().items():
             if "running" in k or "num_batches" in k:
                 assert np.array_equal(v.numpy(), G[tag + "_s_" + k]), k
+
+
+def test_mirror_container_accepts_n_groups(golden_nn):
+    """dotsboxesaz_amd.nn.ResNetZero(params) with n_groups > 1 keeps the reference's state_dict keys and shapes (the grouped golden
+    loads with strict=True), and the engine-side expansion of a grouped weight is the dense block-diagonal matrix."""
+    from dotsboxesaz_amd import nn as dnn
+    from dotsboxesaz_amd.engine import _dense_from_grouped
+    g = golden_nn
+    r, c, ch, nb, hc, vf, ng = [int(x) for x in g["groups33_cfg"]]
+    m = dnn.ResNetZero(dnn.resnet_params(r, c, ch, nb, hc, vf, n_groups=ng))
+    sd = {k[len("groups33_w_"):]: torch.tensor(g[k]) for k in g.files if k.startswith("groups33_w_")}
+    m.load_state_dict(sd, strict=True)
+    w = g["groups33_w_resnet.resblocks.0.conv1.weight"]
+    d = _dense_from_grouped(w, ch)
+    x = torch.randn(3, ch, 4, 4)
+    ref = torch.nn.functional.conv2d(x, torch.tensor(w), padding=1, groups=ng)
+    assert torch.equal(torch.nn.functional.conv2d(x, torch.tensor(d), padding=1), ref) or \
+        float((torch.nn.functional.conv2d(x, torch.tensor(d), padding=1) - ref).abs().max()) < 1e-6
+    with pytest.raises(NotImplementedError):
+        dnn.ResNetZero(dnn.resnet_params(r, c, 16, nb, hc, vf, n_groups=3))
