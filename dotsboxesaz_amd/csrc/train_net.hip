@@ -4,7 +4,7 @@
 
 // ====================================================================================
 // The whole network of the training step on this library (nn.py:108-122 under model.train(True)):
-//   x [n][3][H][W] -> bn_input -> conv0 3x3 (3 -> 64) -> bn0 -> ReLU -> the residual tower (above) -> per head conv 1x1
+//   x [n][3][H][W] -> bn_input -> conv0 3x3 (3 -> 64) -> bn0 -> ReLU -> the residual tower (train.hip) -> per head conv 1x1
 //   (64 -> 16) -> bn -> ReLU -> flatten -> policy: fc -> log_softmax; value: fc0 -> ReLU -> fc1 -> tanh
 // and its backward.  Everything stays in the tower's row layout ([n*HW][channels]): no NCHW <-> rows transposes, the two
 // heads share one 32-channel row (policy channels 0..15, value 16..31) and one fully connected GEMM over the combined row
@@ -20,7 +20,7 @@ struct dbaz_net_buffers {
     int hc = 0, A = 0, VF = 0, NO = 0, NOp = 0, KF = 0, maxN = 0;
     float *Y0 = nullptr;                 // [maxN*HW][64] conv0 output
     unsigned long long *mask0 = nullptr; // ReLU mask of the stem
-    float *st = nullptr;                 // small floats: in_mean[4] in_invstd[4] mean0[64] invstd0[64] mean_h[32] invstd_h[32] (+ packed Wh[64][32], bh[32], W0t[27][64])
+    float *st = nullptr;                 // small floats (offsets ST_*): in_mean[4] in_invstd[4] mean0[64] invstd0[64] mean_h[32] invstd_h[32] bh[32] Wh[64][32]
     double *ws = nullptr;                // bn2d workspace of bn_input + partial rows of the head kernels
     float *Yh = nullptr, *Hh = nullptr;  // [maxN*HW][32] head conv output, after bn + ReLU
     float *dHh = nullptr;                // [maxN*HW][32] gradient of Hh, then of Yh (in place)
