@@ -7,6 +7,7 @@ gradient tensors and calls the C ABI with their device pointers on its current s
 conv3x3, batch statistics, normalisation, ReLU, skip connections and all their gradients -- runs in train.hip.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -32,6 +33,8 @@ class TowerTrainer:
             msg = self._L.dbaz_trainer_last_error(None)
             raise TrainerError(msg.decode() if msg else "dbaz_trainer_create failed (%d)" % rc)
         self.h = h
+        global handles_created
+        handles_created += 1
         self.rows, self.cols, self.channels, self.blocks, self.max_batch, self.device = rows, cols, channels, blocks, max_batch, device
         self.generation = 0  # id of the forward pass whose activations the handle holds (a handle holds ONE)
 
@@ -125,7 +128,26 @@ class _TowerFn(torch.autograd.Function):
         return (None, None, None, gx) + tuple(grads)
 
 
-_trainers = {}  # (id(model), H, W, blocks, device) -> TowerTrainer: one handle per MODEL, so two models of one shape never share activations
+# model -> {(H, W, blocks, device): TowerTrainer}: one handle per MODEL (two models of one shape never share activations), held
+# through a WEAK reference to the model -- coach.train_nn builds a new model every generation (coach.py:71), and a handle is ~5 GB
+# of HBM at batch 4 096: keyed by id(model) the handles of dead models piled up; now a handle goes with its model (an autograd graph
+# that still needs it keeps it alive through ctx.trainer)
+_trainers = weakref.WeakKeyDictionary()
+handles_created = 0  # TowerTrainer handles made so far (tests)
+
+
+def _cached_trainer(model, H, W, blocks, device, batch):
+    per = _trainers.get(model)
+    if per is None:
+        per = {}
+        _trainers[model] = per
+    key = (H, W, blocks, device)
+    tr = per.get(key)
+    if tr is None or tr.max_batch < batch:
+        # (a smaller handle is NOT closed here: an autograd graph may still hold it; it is freed with its last reference)
+        tr = TowerTrainer(H - 1, W - 1, 64, blocks, max(int(batch), 1), device)
+        per[key] = tr
+    return tr
 
 
 def _bn_ok(bn):
@@ -166,12 +188,7 @@ def resblocks_forward(model, x, trainer=None):
     H, W = x.shape[2], x.shape[3]
     tr = trainer
     if tr is None:
-        key = (id(model), H, W, len(blocks), x.device.index or 0)
-        tr = _trainers.get(key)
-        if tr is None or tr.max_batch < x.shape[0]:
-            # (a smaller handle is NOT closed here: an autograd graph may still hold it; it is freed with its last reference)
-            tr = TowerTrainer(H - 1, W - 1, 64, len(blocks), max(int(x.shape[0]), 1), x.device.index or 0)
-            _trainers[key] = tr
+        tr = _cached_trainer(model, H, W, len(blocks), x.device.index or 0, x.shape[0])
     params, rm, rv, nbt = [], [], [], []
     for b in blocks:
         for conv, bn in ((b.conv1, b.bn1), (b.conv2, b.bn2)):
@@ -336,11 +353,7 @@ def network_forward(model, x, trainer=None):
     H, W = x.shape[2], x.shape[3]
     tr = trainer
     if tr is None:
-        key = (id(model), H, W, len(r.resblocks), x.device.index or 0)
-        tr = _trainers.get(key)
-        if tr is None or tr.max_batch < x.shape[0]:
-            tr = TowerTrainer(H - 1, W - 1, 64, len(r.resblocks), max(int(x.shape[0]), 1), x.device.index or 0)
-            _trainers[key] = tr
+        tr = _cached_trainer(model, H, W, len(r.resblocks), x.device.index or 0, x.shape[0])
     single, layers = _net_parameters(model)
     running = _NetRunning(model)
     torch._foreach_add_(running.counters, 1)   # BatchNorm2d.forward: num_batches_tracked += 1

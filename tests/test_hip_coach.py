@@ -91,11 +91,15 @@ def test_generation_loop_trains_through_the_hip_tower(tmp_path):
     torch.manual_seed(0)
     np.random.seed(0)
     train_tower._trainers.clear()
+    made = train_tower.handles_created
     coach = Coach(params, 3, 3, n_slots=32)
     w = Writer()
     log = coach.learn_to_play(0, 1, writer=w)
     assert [r["generation"] for r in log] == [0, 1] and log[1]["last_batch_idx"] > 0
-    assert len(train_tower._trainers) == 1                        # the HIP tower ran the training steps
+    assert train_tower.handles_created == made + 1                # the HIP tower ran the training steps (one handle, one model)
+    import gc
+    gc.collect()
+    assert len(train_tower._trainers) == 0                        # ... and went with the generation's model (train_nn builds a new one each time)
     losses = [v for t, v, _ in w.s if t == "loss/total/train"]
     assert len(losses) == log[1]["last_batch_idx"] and np.all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3])
     ck = torch.load(params["nn"]["chkpts_filename"].format(1), map_location="cpu", weights_only=True)

@@ -466,3 +466,29 @@ def test_hip_sgd_is_torch_sgd():
     before = pc[0].detach().clone()
     oc.step()
     assert torch.allclose(pc[0], before - 0.1)
+
+
+def test_a_handle_goes_with_its_model():
+    """coach.train_nn builds a new model every generation: its trainer handle (activations of a whole batch in HBM) must not outlive
+    it.  The cache holds models weakly; the device memory of a dead model's handle is returned."""
+    import gc
+    from dotsboxesaz_amd import nn as dnn, train as T, train_tower
+    train_tower._trainers.clear()
+    gc.collect()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    x = (torch.rand(256, 3, 7, 7, device="cuda") < 0.4).float()
+    for _ in range(3):      # three "generations": a new model each, as coach.py:71 does
+        m = dnn.ResNetZero(dnn.resnet_params(6, 6, 64, 4)).cuda().train(True)
+        p, v = T.training_forward(m, x)
+        (p.sum() + v.sum()).backward()
+        torch.cuda.synchronize()
+        assert len(train_tower._trainers) == 1
+        del m, p, v
+        gc.collect()
+    assert len(train_tower._trainers) == 0
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    # one handle of this size is ~0.3 GB: nothing of that order may be left behind
+    assert free0 - free1 < 64 * 2 ** 20, (free0, free1)

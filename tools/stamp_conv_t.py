@@ -20,7 +20,7 @@ for _ in range(5):
     y = train_tower.resblocks_forward(m, x)
 torch.cuda.synchronize()
 L = _lib.load()
-t = [v for v in train_tower._trainers.values()][0]
+t = [tr for per in train_tower._trainers.values() for tr in per.values()][0]
 S = 256 // 49
 n_wg = (n + S - 1) // S
 out = np.zeros((n_wg, 8, 8), np.uint64)

@@ -21,7 +21,7 @@ for _ in range(3):
     y.backward(torch.randn_like(y) * 1e-3)
 torch.cuda.synchronize()
 L = _lib.load()
-t = [v for v in train_tower._trainers.values()][0]
+t = [tr for per in train_tower._trainers.values() for tr in per.values()][0]
 n_wg = 256
 out = np.zeros((n_wg, 8, 8), np.uint64)
 L.dbaz_debug_trainer_wgrad_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
