@@ -98,6 +98,7 @@ class Coach:
 
         train_ds = self.store.dataset(train=True, min_generation=gmin, n_samples=int(n_samples * split), pos_average=avg)
         val_ds = self.store.dataset(train=False, min_generation=gmin, n_samples=int(n_samples * (1 - split)), pos_average=avg)
+        self.store.drop_before(gmin)  # (the window's lower edge only moves forward: older rows would stay in HBM for nothing)
         return wrapper.train(train_ds, val_ds if len(val_ds) else None, writer, generation)
 
     def learn_to_play(self, from_generation, to_generation, last_model_elo=1200, start_train=False, writer=None):

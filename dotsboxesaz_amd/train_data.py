@@ -51,6 +51,15 @@ class ReplayStore:
         """slot: which of the engine's resident datasets to build into (default: 0 for train, 1 for validation)."""
         return ReplayDataset(self, train, min_generation, n_samples, pos_average, slot)
 
+    def drop_before(self, generation):
+        """Releases the rows of generations older than `generation`.  The reference's HDF file only grows; here the window lives in
+        HBM, and the window's lower edge (coach.py:148-149, train.window_where) never moves back, so what lies below it is dead:
+        a long run keeps at most the ~21 generations of the widest window on the device.  Returns the number of generations dropped."""
+        keep = [c for c in self.chunks if c["generation"] >= generation]
+        dropped = len(self.chunks) - len(keep)
+        self.chunks = keep
+        return dropped
+
 
 class ReplayDataset:
     """utils.HDFStoreDataset over rows in HBM.  Building it runs the HIP dataset kernels; an engine

@@ -105,3 +105,21 @@ def test_lr_scheduler_and_window():
     assert [s(g) for g in (0, 19, 20, 49, 50, 80)] == [1e-2, 1e-2, 1e-3, 1e-3, 1e-4, 1e-4]
     # coach.py:148-149
     assert [T.window_where(g) for g in (0, 3, 4, 6, 10, 36, 40)] == [0, 0, 0, 1, 3, 16, 20]
+
+
+def test_replay_store_drops_what_lies_below_the_window():
+    """The training window's lower edge (coach.py:148-149) only moves forward; ReplayStore.drop_before releases the generations below
+    it (host logic only: no GPU)."""
+    import torch
+    from dotsboxesaz_amd import train as T
+    from dotsboxesaz_amd.train_data import ReplayStore
+    edges = [T.window_where(g) for g in range(0, 80)]
+    assert all(b >= a for a, b in zip(edges, edges[1:])) and edges[0] == 0 and max(g - e for g, e in enumerate(edges)) == 20
+    st = ReplayStore(None)
+    np.random.seed(0)
+    for g in range(30):
+        st.add_generation(g, torch.zeros((10 + g, 8), dtype=torch.uint8))
+        dropped = st.drop_before(T.window_where(g))
+        assert dropped in (0, 1)
+        assert [c["generation"] for c in st.chunks] == list(range(T.window_where(g), g + 1))
+    assert len(st.chunks) <= 21
