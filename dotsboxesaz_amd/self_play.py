@@ -347,12 +347,14 @@ def compute_elo(elo_params, params, generations, elos, nn_classes=None, rows=Non
             mdl.load_parameters(gen)  # compare_models: generation g itself (self_play.py:190)
     eng = Engine(rows, cols, n_slots or max(1, min(n_games, 4096)), evaluator=models[0].kind, evaluator2=models[1].kind,
                  match_play=True, device=device, nn_precision=nn_precision, **kw)
-    for i, mdl in enumerate(models):
-        eng.load_state_dict(mdl.state_dict(), mdl.kind, model=i, **mdl.shape)
-    eng.selfplay_start(n_games, 0)
-    eng.run()
-    got = eng.fetch_samples()
-    eng.close()
+    try:
+        for i, mdl in enumerate(models):
+            eng.load_state_dict(mdl.state_dict(), mdl.kind, model=i, **mdl.shape)
+        eng.selfplay_start(n_games, 0)
+        eng.run()
+        got = eng.fetch_samples()
+    finally:
+        eng.close()
     n0, n1 = match_winners(got, generations)
     e0, e1 = elo_rating2(elos[0], elos[1], n0, n1, K=30)
     decided = n0 + n1
